@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- ICP iterations/s and correspondences/s on 370k-point ETH-Apartment-class pairs.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched through
+torch.distributed.run, one rank per GPU (RCCL).  Prints ONE JSON line on rank 0.
+
+A "step" is one LinearICPOptimizer::estimatePose on one scan pair: BASELINE.json configs[1] -- synthetic
+ETH-Apartment-like pair (344 x 1077 = 370 488 points each), exact k-NN matching,
+point-to-plane linear solve, maxDist^2 = 10 (main.cpp:361), 50 iterations (main.cpp:366), rejection ON, constant
+weights, no multi-resolution.  Clouds are uploaded (icp_set_target / icp_set_source) BEFORE the timed region;
+the timed region is icp_run only (matching + weighting + rejection + system build + solve, 50 x).
+N GPUs: every rank aligns its own pair (pair index = rank, weak scaling, independent pairs as in main.cpp:411),
+then ONE all_gather of the 16-float poses per step (RCCL over xGMI).
+value = ICP iterations/s summed over all ranks; correspondences/s = value x 370 488.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "icp-variants_amd", "python")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np   # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VALU_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def cpu_baseline(pair, n_iter=2, threads=None):
+    """Oracle (CPU restatement) timed on the host cores: exact kd-tree matcher (stand-in for the FLANN kd-tree the
+    reference instantiates, NearestNeighbor.h:122-207) + reference-shaped fp32 dense solve.  Bounded sample."""
+    from oracle import oracle as orc
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = threads or max(1, min(16, ncpu))
+    orc.set_num_threads(threads)
+    prm = orc.make_params(metric=1, n_iterations=n_iter, max_distance=10.0, solver_mode=0, knn_kdtree=1)
+    t0 = time.perf_counter()
+    kd = orc.KdTree(pair["tgt_pts"])                       # buildIndex, once per pair (ICPOptimizer.h:532-535)
+    t_build = time.perf_counter() - t0
+    prm.kdtree = kd.h
+    t0 = time.perf_counter()
+    pose, recs = orc.estimate_pose(prm, pair["src_pts"], pair["src_nrm"], None, pair["tgt_pts"], pair["tgt_nrm"], None, np.eye(4, dtype=np.float32))
+    dt = time.perf_counter() - t0
+    its = len(recs) / dt
+    return {"value": its, "unit": "ICP iterations/s", "cores": threads, "kind": "port",
+            "sample": "%d full ICP iterations of the same 370488-point pair (CPU oracle: exact kd-tree k-NN on %d OpenMP threads, "
+                      "weighting/rejection/compaction + fp32 4n x 6 QR/Jacobi-SVD solve on 1 thread); kd-tree build %.3f s excluded, "
+                      "match %.3f s/iter, rest %.3f s/iter" % (len(recs), threads, t_build,
+                                                                 float(np.mean([r["seconds_match"] for r in recs])),
+                                                                 float(np.mean([r["seconds_rest"] for r in recs])))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--iterations", type=int, default=50, help="ICP iterations per step (main.cpp:366)")
+    ap.add_argument("--knn", choices=["brute", "grid"], default=os.environ.get("ICP_BENCH_KNN", "brute"))
+    ap.add_argument("--n-tilt", type=int, default=344)
+    ap.add_argument("--n-beam", type=int, default=1077)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from icp_amd import binding, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ICP hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- workload: pair (rank, rank+1) of the synthetic 45-scan sequence -------------------------
+    pair = synth.eth_like_pair(rank % 44, n_tilt=args.n_tilt, n_beam=args.n_beam)
+    n_src, n_tgt = len(pair["src_pts"]), len(pair["tgt_pts"])
+    opt = binding.LinearICPOptimizer(local_rank)
+    opt.setMatchingMethod(0); opt.setMatchingMaxDistance(10.0)          # main.cpp:360-361
+    opt.setMetric(1); opt.setNbOfIterations(args.iterations)             # main.cpp:364-366
+    opt.setWeightingMethod(0); opt.setRejectionMethod(1)
+    opt.setKnnBackend(1 if args.knn == "grid" else 0)
+    ctx = opt.ctx
+    ctx.push_params()
+    ctx.set_target(pair["tgt_pts"], pair["tgt_nrm"], None)              # resident in HBM before the timed region
+    ctx.set_source(pair["src_pts"], pair["src_nrm"], None)
+    eye = binding.pose_to_c(np.eye(4, dtype=np.float32))
+    poses_dev = torch.zeros(16, dtype=torch.float32, device="cuda")
+    gathered = [torch.zeros(16, dtype=torch.float32, device="cuda") for _ in range(world)] if world > 1 else None
+
+    def step():
+        pose = eye.copy()
+        ctx.run_raw(pose)                                               # 50 ICP iterations, no host round trip inside
+        if world > 1:
+            poses_dev.copy_(torch.from_numpy(pose))
+            dist.all_gather(gathered, poses_dev)                        # the single pose gather of the batch
+        return pose
+
+    for _ in range(args.warmup):
+        step()
+    acc = dict(match_ms=0.0, weight_reject_build_ms=0.0, solve_ms=0.0, total_ms=0.0, iterations=0)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pose = step()
+        tm = ctx.timing()
+        for k in acc:
+            acc[k] += tm[k]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    iters_total = world * args.steps * args.iterations
+    value = iters_total / elapsed
+    # ---- roofline of the dominant kernel (k-NN matcher), HIP events on the context's own stream ----
+    launches = max(acc["iterations"], 1)
+    knn_ms = acc["match_ms"] / launches
+    alg_bytes = 12 * n_src + 12 * n_tgt + 8 * n_src                    # read src xyz + tgt xyz, write Match
+    achieved = alg_bytes / (knn_ms * 1e-3) / 1e9
+    pairs = float(n_src) * float(n_tgt)
+    flops = pairs * 8.0                                                 # 3 sub + 3 mul + 2 add per pair (no FMA: bit-exact contract)
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")       # HBM bytes/launch from a separate rocprofv3 --pmc pass
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            if tj.get("knn") == args.knn and tj.get("n_src") == n_src:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    gt = pair["gt"]
+    P = binding.pose_from_c(pose).astype(np.float64)
+    dR = P[:3, :3] @ gt[:3, :3].T
+    rot_err = float(np.arctan2(0.5 * np.linalg.norm([dR[2, 1] - dR[1, 2], dR[0, 2] - dR[2, 0], dR[1, 0] - dR[0, 1]]), (np.trace(dR) - 1) / 2))
+    trans_err = float(np.linalg.norm(P[:3, 3] - gt[:3, 3]))
+
+    out = {
+        "metric": "ICP iterations/s (k-NN + point-to-plane linear, 370k-point ETH-Apartment-like pair)",
+        "value": value, "unit": "ICP iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: synthetic ETH-Apartment-like pair (rank, rank+1), %d x %d pts, exact %s k-NN, "
+                               "point-to-plane linear, maxDist^2=10, %d iterations/step, rejection on" % (n_src, n_tgt, args.knn, args.iterations),
+                   "pairs_per_step": world, "iterations_per_step": args.iterations, "knn_backend": args.knn},
+        "correspondences_per_s": value * n_src,
+        "ms_per_iteration": elapsed / (args.steps * args.iterations) * 1e3,
+        "stage_ms_per_iteration": {"match": acc["match_ms"] / launches, "weight_reject_build": acc["weight_reject_build_ms"] / launches,
+                                   "solve": acc["solve_ms"] / launches},
+        "roofline": {"kernel": "k_knn_%s" % args.knn, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": knn_ms},
+        "valu_roofline": {"pair_evals_per_s": pairs / (knn_ms * 1e-3) if args.knn == "brute" else None,
+                          "achieved_tflops": flops / (knn_ms * 1e-3) / 1e12 if args.knn == "brute" else None,
+                          "peak_tflops": FP32_VALU_PEAK_TFLOPS,
+                          "note": "brute force is FP32-VALU-bound, not HBM-bound (SURVEY.md 8d); 8 non-fused flop per pair"},
+        "pose_error_vs_gt": {"rot_rad": rot_err, "trans_m": trans_err},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(pair)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

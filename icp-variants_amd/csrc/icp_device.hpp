@@ -1,0 +1,732 @@
+// =====================================================================================
+// icp_device.hpp -- hand-written HIP kernels of the ICP hot path for gfx950 (MI355X, wave64).
+//
+// Build contract: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (no fast-math): every fp32
+// result is one IEEE rounding per operation, in the operation order of the CPU restatement
+// (oracle/icp_oracle.cpp), so match indices / distances / weights are bit-identical to it.
+// fp32 sqrt and divide are correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+//
+// Kernel map (reference file:line relative to icp-variants/ of the reference):
+//   k_deinterleave      AoS -> SoA upload conversion (+ colour features NearestNeighbor.h:212-221)
+//   k_knn_brute<DIM>    transformPoints (utils.h:106-118) fused with exact 1-NN, first-minimum argmin
+//                       (NearestNeighbor.h:81-97 semantics, squared L2 + squared threshold :181-185);
+//                       DIM=6 adds rgb/255 (NearestNeighbor.h:209-303)
+//   k_knn_finalize      merges target-split partial results (packed u64 atomicMin) into Match records
+//   k_projective        NearestNeighborSearchProjective::queryMatches (NearestNeighbor.h:333-421)
+//   k_post              transformNormals (utils.h:122-133) + applyWeights (weighting.h:39-99) +
+//                       pruneCorrespondences (ICPOptimizer.h:157-174) + validity filter (:594-610) +
+//                       normal-equation / moment accumulation (ICPOptimizer.h:676-751, ProcrustesAligner.h:43-55)
+//   k_sym_accumulate    second pass of the symmetric objective with the means (ICPOptimizer.h:797-853)
+//   k_reduce_solve      fixed-order reduction of block partials + fp64 solve + pose composition
+//                       (ICPOptimizer.h:614-620,753-781,855-897; ProcrustesAligner.h:56-66)
+//   k_rmse_partial      ConvergenceMeasure::rmseAlignmentError (ConvergenceMeasure.h:50-66)
+// =====================================================================================
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+#include "../../include/icp_hip.h"
+
+namespace icpdev {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int WAVE = 64;
+constexpr int KNN_CH = 16;          // targets per filter chunk (one s_load_dwordx16 per coordinate)
+constexpr int NSUM = 40;            // doubles per block partial (34 used)
+constexpr int SUM_N = 0, SUM_S = 1, SUM_D = 4, SUM_M = 7;   // count, sum s, sum d, metric-specific block
+constexpr int POST_THREADS = 256;
+
+// Device-resident pose: column-major 4x4 (Eigen layout) + row-major (R^-1)^T for the normals.
+struct PoseState {
+    float pose[16];
+    float nmat[9];
+    float mean_s[3];       // unweighted means of the current valid correspondences (symmetric ICP)
+    float mean_d[3];
+    float pad;
+};
+
+struct SoA3 { const float* x; const float* y; const float* z; };
+
+__device__ __forceinline__ bool finite3(float a, float b, float c) {
+    return isfinite(a) && isfinite(b) && isfinite(c);
+}
+
+// utils.h:113-115 : ((R_i0*x + R_i1*y) + R_i2*z) + t_i  (sequential, fp32, no contraction)
+__device__ __forceinline__ void xform_point(const float* __restrict__ P, float x, float y, float z, float& ox, float& oy, float& oz) {
+    ox = ((P[0] * x + P[4] * y) + P[8] * z) + P[12];
+    oy = ((P[1] * x + P[5] * y) + P[9] * z) + P[13];
+    oz = ((P[2] * x + P[6] * y) + P[10] * z) + P[14];
+}
+// utils.h:128-130 with the hoisted (R^-1)^T
+__device__ __forceinline__ void xform_normal(const float* __restrict__ N, float x, float y, float z, float& ox, float& oy, float& oz) {
+    ox = (N[0] * x + N[1] * y) + N[2] * z;
+    oy = (N[3] * x + N[4] * y) + N[5] * z;
+    oz = (N[6] * x + N[7] * y) + N[8] * z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// AoS (N x 3 fp32) -> SoA planes.  pad_to > n fills [n, pad_to) with pad_value (+inf for targets so a
+// padded slot can never win the argmin).
+__global__ void k_deinterleave3(const float* __restrict__ aos, int n, int pad_to, float pad_value,
+                                float* __restrict__ x, float* __restrict__ y, float* __restrict__ z) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { x[i] = aos[(size_t)i * 3]; y[i] = aos[(size_t)i * 3 + 1]; z[i] = aos[(size_t)i * 3 + 2]; }
+    else if (i < pad_to) { x[i] = pad_value; y[i] = pad_value; z[i] = pad_value; }
+}
+// RGBA bytes -> packed u32 + colour features (color_scale*color_normalize)*float(c), NearestNeighbor.h:212-221
+__global__ void k_colors(const uint8_t* __restrict__ rgba, int n, int pad_to, uint32_t* __restrict__ packed,
+                         float* __restrict__ cr, float* __restrict__ cg, float* __restrict__ cb) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float color_normalize = 1 / float(255);
+    const float color_scale = 1;
+    if (i < n) {
+        uint32_t v = ((const uint32_t*)rgba)[i];
+        packed[i] = v;
+        cr[i] = color_scale * color_normalize * (float)(int)(v & 0xFF);
+        cg[i] = color_scale * color_normalize * (float)(int)((v >> 8) & 0xFF);
+        cb[i] = color_scale * color_normalize * (float)(int)((v >> 16) & 0xFF);
+    } else if (i < pad_to) { cr[i] = 0.f; cg[i] = 0.f; cb[i] = 0.f; }
+}
+
+__global__ void k_fill_u64(unsigned long long* p, int n, unsigned long long v) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact brute-force 1-NN.  One lane = one query; the target planes are wave-uniform and reach the
+// VALU as SGPR operands (s_load_dwordx16 per coordinate per chunk -- no LDS, no VGPR staging).
+// Hot loop per PAIR of targets: 5 v_pk_add_f32 + 3 v_pk_mul_f32 + v_min3_f32 (no index tracking);
+// a chunk whose minimum beats the lane's running best is rescanned with the reference's
+// sequential strict-< loop, which alone defines the result (the packed pass is only a filter:
+// v_pk_* and scalar ops round identically, so it has no false negatives).
+// Block = 4 waves sharing the same 64 queries; wave w scans quarter w of the block's target
+// segment; blockIdx.y splits the target range further for small query counts (merged with a
+// packed (d2 bits, index) 64-bit atomicMin = lexicographic first-minimum).
+struct KnnParams {
+    const float* sx; const float* sy; const float* sz;       // source planes (untransformed unless pretransformed)
+    const float* scr; const float* scg; const float* scb;    // source colour features (DIM=6)
+    const int* sel;                                          // optional selection (multires); nullptr = identity
+    int n;                                                   // queries
+    const float* tx; const float* ty; const float* tz;       // target planes, padded with +inf to mpad
+    const float* tcr; const float* tcg; const float* tcb;
+    int mpad;                                                // multiple of KNN_CH
+    const PoseState* ps; int pretransformed;
+    float max_dist;
+    icp_match_t* out; float* d2_out;                           // direct outputs (nseg == 1)
+    unsigned long long* best64;                              // packed partial results (nseg > 1)
+    int nseg;
+};
+
+template <int DIM>
+__global__ __launch_bounds__(256) void k_knn_brute(const KnnParams kp) {
+    __shared__ float sd[4][WAVE];
+    __shared__ int si[4][WAVE];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = blockIdx.x * WAVE + lane;
+    const int kk = k < kp.n ? k : kp.n - 1;
+    const int i = kp.sel ? kp.sel[kk] : kk;
+    float px = kp.sx[i], py = kp.sy[i], pz = kp.sz[i];
+    if (!kp.pretransformed) { float a, b, c; xform_point(kp.ps->pose, px, py, pz, a, b, c); px = a; py = b; pz = c; }
+    float pr = 0.f, pg = 0.f, pb = 0.f;
+    if (DIM == 6) { pr = kp.scr[i]; pg = kp.scg[i]; pb = kp.scb[i]; }
+    const f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz};
+    const f2 pr2 = {pr, pr}, pg2 = {pg, pg}, pb2 = {pb, pb};
+
+    const int nch = kp.mpad / KNN_CH;
+    const int s0 = (int)(((long long)nch * blockIdx.y) / kp.nseg), s1 = (int)(((long long)nch * (blockIdx.y + 1)) / kp.nseg);
+    const int c0 = s0 + ((s1 - s0) * w) / 4, c1 = s0 + ((s1 - s0) * (w + 1)) / 4;
+
+    float best = FLT_MAX; int bi = -1;
+    for (int c = c0; c < c1; c++) {
+        const int j0 = c * KNN_CH;
+        float mm = FLT_MAX;
+#pragma unroll
+        for (int t = 0; t < KNN_CH; t += 2) {
+            f2 qx = *(const f2*)(kp.tx + j0 + t), qy = *(const f2*)(kp.ty + j0 + t), qz = *(const f2*)(kp.tz + j0 + t);
+            f2 dx = px2 - qx, dy = py2 - qy, dz = pz2 - qz;
+            f2 s = (dx * dx + dy * dy) + dz * dz;
+            if (DIM == 6) {
+                f2 qr = *(const f2*)(kp.tcr + j0 + t), qg = *(const f2*)(kp.tcg + j0 + t), qb = *(const f2*)(kp.tcb + j0 + t);
+                f2 dr = pr2 - qr, dg = pg2 - qg, db = pb2 - qb;
+                s = ((s + dr * dr) + dg * dg) + db * db;
+            }
+            mm = fminf(fminf(mm, s.x), s.y);
+        }
+        if (mm < best) {
+            for (int t = 0; t < KNN_CH; t++) {
+                float dx = px - kp.tx[j0 + t], dy = py - kp.ty[j0 + t], dz = pz - kp.tz[j0 + t];
+                float d = (dx * dx + dy * dy) + dz * dz;
+                if (DIM == 6) {
+                    float dr = pr - kp.tcr[j0 + t], dg = pg - kp.tcg[j0 + t], db = pb - kp.tcb[j0 + t];
+                    d = ((d + dr * dr) + dg * dg) + db * db;
+                }
+                if (d < best) { best = d; bi = j0 + t; }       // strict: first minimum (NearestNeighbor.h:87)
+            }
+        }
+    }
+    sd[w][lane] = best; si[w][lane] = bi;
+    __syncthreads();
+    if (w == 0 && k < kp.n) {
+#pragma unroll
+        for (int v = 1; v < 4; v++) { float d = sd[v][lane]; int j = si[v][lane]; if (d < best) { best = d; bi = j; } }
+        if (kp.nseg == 1) {
+            icp_match_t m;
+            if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }   // NearestNeighbor.h:93-96,182-185
+            kp.out[k] = m;
+            if (kp.d2_out) kp.d2_out[k] = best;
+        } else if (bi >= 0) {
+            unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned int)bi;
+            atomicMin(kp.best64 + k, key);
+        }
+    }
+}
+
+__global__ void k_knn_finalize(const unsigned long long* __restrict__ best64, int n, float max_dist,
+                               icp_match_t* __restrict__ out, float* __restrict__ d2_out) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    unsigned long long key = best64[k];
+    float best = __uint_as_float((unsigned int)(key >> 32));
+    int bi = (int)(unsigned int)(key & 0xFFFFFFFFu);
+    if (bi == -1) best = FLT_MAX;
+    icp_match_t m;
+    if (best <= max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
+    out[k] = m;
+    if (d2_out) d2_out[k] = best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Projective matcher, NearestNeighbor.h:333-421.  One lane = one query; the 25x25 window of the
+// organised target is read through L1/L2 (neighbouring lanes' windows overlap almost entirely).
+struct ProjParams {
+    const float* sx; const float* sy; const float* sz; const int* sel; int n;
+    const float* tx; const float* ty; const float* tz; int width; int height;
+    float fx, fy, mx, my; int window;
+    const PoseState* ps; int pretransformed; float max_dist;
+    icp_match_t* out; float* d2_out;
+};
+
+__global__ __launch_bounds__(256) void k_projective(const ProjParams pp) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= pp.n) return;
+    const int i = pp.sel ? pp.sel[k] : k;
+    float px = pp.sx[i], py = pp.sy[i], pz = pp.sz[i];
+    if (!pp.pretransformed) { float a, b, c; xform_point(pp.ps->pose, px, py, pz, a, b, c); px = a; py = b; pz = c; }
+    icp_match_t m; float best = FLT_MAX;
+    if (px == -INFINITY) {                                   // :372-373 leaves the value-initialised Match{0, 0.f}
+        m.idx = 0; m.weight = 0.f;
+    } else {
+        const float uf = roundf(((px * pp.fx) / pz) + pp.mx);    // :378
+        const float vf = roundf(((py * pp.fy) / pz) + pp.my);    // :379
+        const float wf = (float)pp.window;
+        int bi = -1;
+        // unsigned underflow (:385-386): a window starting below 0 never runs; NaN / negative / huge => no match
+        if (uf >= wf && vf >= wf && uf < 2147483648.f && vf < 2147483648.f) {
+            const long long u0 = (long long)uf - pp.window, u1 = (long long)uf + pp.window;
+            const long long v0 = (long long)vf - pp.window, v1 = (long long)vf + pp.window;
+            const int ve = (int)(v1 < (long long)pp.height - 1 ? v1 : (long long)pp.height - 1);
+            const int ue = (int)(u1 < (long long)pp.width - 1 ? u1 : (long long)pp.width - 1);
+            if (v0 < pp.height && u0 < pp.width) {
+                for (int v = (int)v0; v <= ve; v++) {
+                    const int row = v * pp.width;
+                    for (int u = (int)u0; u <= ue; u++) {
+                        const int j = row + u;
+                        const float qx = pp.tx[j];
+                        if (qx == -INFINITY) continue;           // :392
+                        const float dx = px - qx, dy = py - pp.ty[j], dz = pz - pp.tz[j];
+                        const float d = dx * dx + (dy * dy + dz * dz);     // :396 Eigen squaredNorm tree
+                        if (d < best) { best = d; bi = j; }      // :399
+                    }
+                }
+            }
+        }
+        if (best <= pp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }   // :407-415
+    }
+    pp.out[k] = m;
+    if (pp.d2_out) pp.d2_out[k] = best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Deterministic block reduction of NV doubles per thread: wave shuffle tree, then the 4 wave
+// results are added in wave order by wave 0.  Result valid in thread 0.
+template <int NV>
+__device__ __forceinline__ void block_reduce(double (&v)[NV], double* lds /* [4][NV] */) {
+#pragma unroll
+    for (int a = 0; a < NV; a++) {
+        double x = v[a];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
+        v[a] = x;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < NV; a++) lds[w * NV + a] = v[a];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int a = 0; a < NV; a++) v[a] = ((lds[a] + lds[NV + a]) + lds[2 * NV + a]) + lds[3 * NV + a];
+    }
+}
+
+// Rows of the reference's 4n x 6 system in fp32, then their contribution to J^T J (upper triangle,
+// 21) and J^T r (6) in fp64.  kind 0: point-to-plane (ICPOptimizer.h:698-750); kind 1: symmetric
+// (ICPOptimizer.h:806-852, s/d already centred, n = n_t + n_s).
+__device__ __forceinline__ void accumulate_rows(int kind, float s0, float s1, float s2, float d0, float d1, float d2,
+                                                float n0, float n1, float n2, float w, double* acc /* 27 */) {
+    float A0[6], b0;
+    if (kind == 0) {
+        A0[0] = n2 * s1 - n1 * s2; A0[1] = n0 * s2 - n2 * s0; A0[2] = n1 * s0 - n0 * s1;
+        b0 = ((n0 * d0 + n1 * d1) + n2 * d2) - ((n0 * s0 + n1 * s1) + n2 * s2);
+    } else {
+        const float e0 = s0 + d0, e1 = s1 + d1, e2 = s2 + d2;
+        const float g0 = d0 - s0, g1 = d1 - s1, g2 = d2 - s2;
+        A0[0] = e1 * n2 - e2 * n1; A0[1] = e2 * n0 - e0 * n2; A0[2] = e0 * n1 - e1 * n0;
+        b0 = g0 * n0 + (g1 * n1 + g2 * n2);
+    }
+    A0[3] = n0; A0[4] = n1; A0[5] = n2;
+    const float f0 = 1.0f * w, f1 = 0.1f * w;             // LAMBDA_PLANE/SYMMETRIC = 1, LAMBDA_POINT = 0.1 (:737-738,:839-840)
+    float R[4][6], b[4];
+#pragma unroll
+    for (int c = 0; c < 6; c++) R[0][c] = A0[c] * f0;
+    b[0] = b0 * f0;
+    R[1][0] = 0.f * f1;  R[1][1] = s2 * f1;    R[1][2] = (-s1) * f1; R[1][3] = 1.f * f1; R[1][4] = 0.f * f1; R[1][5] = 0.f * f1; b[1] = (d0 - s0) * f1;
+    R[2][0] = (-s2) * f1; R[2][1] = 0.f * f1;  R[2][2] = s0 * f1;    R[2][3] = 0.f * f1; R[2][4] = 1.f * f1; R[2][5] = 0.f * f1; b[2] = (d1 - s1) * f1;
+    R[3][0] = s1 * f1;   R[3][1] = (-s0) * f1; R[3][2] = 0.f * f1;   R[3][3] = 0.f * f1; R[3][4] = 0.f * f1; R[3][5] = 1.f * f1; b[3] = (d2 - s2) * f1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int c = a; c < 6; c++) { acc[q] += (double)R[r][a] * (double)R[r][c]; q++; }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[21 + a] += (double)R[r][a] * (double)b[r];
+    }
+}
+
+struct PostParams {
+    const float* sx; const float* sy; const float* sz;
+    const float* snx; const float* sny; const float* snz;
+    const uint32_t* srgba; const int* sel; int n;
+    const float* tx; const float* ty; const float* tz;
+    const float* tnx; const float* tny; const float* tnz; const uint32_t* trgba;
+    const PoseState* ps;
+    icp_match_t* matches;          // in: after matching; out: after weighting + pruning
+    int metric, weighting, rejection;
+    float max_dist, cos_reject;  // cos_reject: largest float c with acosf(c) > 60 deg on this host's libm
+    double* partials;            // [gridDim.x][NSUM]
+};
+
+// One fused pass over the correspondences (weight, reject, filter, accumulate).
+__global__ __launch_bounds__(POST_THREADS) void k_post(const PostParams pp) {
+    __shared__ double lds[4 * 34];
+    double acc[34];
+#pragma unroll
+    for (int a = 0; a < 34; a++) acc[a] = 0.0;
+    const float* __restrict__ P = pp.ps->pose;
+    const float* __restrict__ N = pp.ps->nmat;
+    for (int k = blockIdx.x * POST_THREADS + threadIdx.x; k < pp.n; k += gridDim.x * POST_THREADS) {
+        icp_match_t m = pp.matches[k];
+        if (m.idx < 0) continue;
+        const int i = pp.sel ? pp.sel[k] : k;
+        float s0, s1, s2, ns0, ns1, ns2;
+        xform_point(P, pp.sx[i], pp.sy[i], pp.sz[i], s0, s1, s2);
+        xform_normal(N, pp.snx[i], pp.sny[i], pp.snz[i], ns0, ns1, ns2);
+        const int j = m.idx;
+        const float d0 = pp.tx[j], d1 = pp.ty[j], d2 = pp.tz[j];
+        const float nt0 = pp.tnx[j], nt1 = pp.tny[j], nt2 = pp.tnz[j];
+        const bool fin_sd = finite3(s0, s1, s2) && finite3(d0, d1, d2);
+        // ---- applyWeights, weighting.h:44-90 ----
+        if (pp.weighting != ICP_WEIGHT_CONSTANT) {
+            float wnew = 0.0f;
+            if (pp.weighting == ICP_WEIGHT_DISTANCES || pp.weighting == ICP_WEIGHT_COLORS) {
+                if (fin_sd) {
+                    const float e0 = s0 - d0, e1 = s1 - d1, e2 = s2 - d2;
+                    const float q = ((e0 * e0 + e1 * e1) + e2 * e2) / pp.max_dist;
+                    wnew += (float)(1.0 - (double)q);          // weighting.h:19
+                }
+            }
+            if (pp.weighting == ICP_WEIGHT_NORMALS) {
+                if (finite3(ns0, ns1, ns2) && finite3(nt0, nt1, nt2))
+                    wnew += ns0 * nt0 + (ns1 * nt1 + ns2 * nt2);   // weighting.h:24 (Eigen dot tree)
+            }
+            if (pp.weighting == ICP_WEIGHT_COLORS) {
+                const uint32_t a = pp.srgba[i], b = pp.trgba[j];
+                const int e0 = (int)(uint8_t)((a & 0xFF) - (b & 0xFF));           // weighting.h:28 uint8 wrap-around
+                const int e1 = (int)(uint8_t)(((a >> 8) & 0xFF) - ((b >> 8) & 0xFF));
+                const int e2 = (int)(uint8_t)(((a >> 16) & 0xFF) - ((b >> 16) & 0xFF));
+                const float cq = (float)(e0 * e0 + e1 * e1 + e2 * e2) / (float)195075;
+                wnew *= (float)(1.0 - (double)cq);             // weighting.h:29,86
+            }
+            m.weight = wnew;
+        }
+        // ---- pruneCorrespondences, ICPOptimizer.h:157-174 ----
+        if (pp.rejection == 1) {
+            const float dt = ns0 * nt0 + (ns1 * nt1 + ns2 * nt2);
+            const float na = sqrtf(ns0 * ns0 + (ns1 * ns1 + ns2 * ns2));
+            const float nb = sqrtf(nt0 * nt0 + (nt1 * nt1 + nt2 * nt2));
+            const float c = dt / (na * nb);
+            // acos(c) > 60deg  <=>  -1 <= c <= cos_reject ; NaN / |c| > 1 => acos is NaN => kept
+            if (c >= -1.0f && c <= pp.cos_reject) m.idx = -1;
+        }
+        pp.matches[k] = m;
+        if (m.idx < 0 || !fin_sd) continue;                    // ICPOptimizer.h:596-598
+        const float w = m.weight;
+        acc[SUM_N] += 1.0;
+        acc[SUM_S] += (double)s0; acc[SUM_S + 1] += (double)s1; acc[SUM_S + 2] += (double)s2;
+        acc[SUM_D] += (double)d0; acc[SUM_D + 1] += (double)d1; acc[SUM_D + 2] += (double)d2;
+        if (pp.metric == ICP_METRIC_POINT_TO_PLANE) {
+            accumulate_rows(0, s0, s1, s2, d0, d1, d2, nt0, nt1, nt2, w, acc + SUM_M);
+        } else if (pp.metric == ICP_METRIC_POINT_TO_POINT) {
+            const double wd = (double)w;
+            acc[SUM_M] += wd;
+            const double ws0 = wd * s0, ws1 = wd * s1, ws2 = wd * s2;
+            acc[SUM_M + 1] += ws0; acc[SUM_M + 2] += ws1; acc[SUM_M + 3] += ws2;
+            acc[SUM_M + 4] += wd * d0; acc[SUM_M + 5] += wd * d1; acc[SUM_M + 6] += wd * d2;
+            acc[SUM_M + 7] += (double)d0 * ws0;  acc[SUM_M + 8] += (double)d0 * ws1;  acc[SUM_M + 9] += (double)d0 * ws2;
+            acc[SUM_M + 10] += (double)d1 * ws0; acc[SUM_M + 11] += (double)d1 * ws1; acc[SUM_M + 12] += (double)d1 * ws2;
+            acc[SUM_M + 13] += (double)d2 * ws0; acc[SUM_M + 14] += (double)d2 * ws1; acc[SUM_M + 15] += (double)d2 * ws2;
+        }
+    }
+    block_reduce<34>(acc, lds);
+    if (threadIdx.x == 0) {
+        double* o = pp.partials + (size_t)blockIdx.x * NSUM;
+#pragma unroll
+        for (int a = 0; a < 34; a++) o[a] = acc[a];
+    }
+}
+
+// Second pass of the symmetric objective: rows need the means of the valid pairs first
+// (ICPOptimizer.h:797-809).  Reads the final matches written by k_post.
+__global__ __launch_bounds__(POST_THREADS) void k_sym_accumulate(const PostParams pp) {
+    __shared__ double lds[4 * 27];
+    double acc[27];
+#pragma unroll
+    for (int a = 0; a < 27; a++) acc[a] = 0.0;
+    const float* __restrict__ P = pp.ps->pose;
+    const float* __restrict__ N = pp.ps->nmat;
+    const float ms0 = pp.ps->mean_s[0], ms1 = pp.ps->mean_s[1], ms2 = pp.ps->mean_s[2];
+    const float md0 = pp.ps->mean_d[0], md1 = pp.ps->mean_d[1], md2 = pp.ps->mean_d[2];
+    for (int k = blockIdx.x * POST_THREADS + threadIdx.x; k < pp.n; k += gridDim.x * POST_THREADS) {
+        const icp_match_t m = pp.matches[k];
+        if (m.idx < 0) continue;
+        const int i = pp.sel ? pp.sel[k] : k;
+        float s0, s1, s2, ns0, ns1, ns2;
+        xform_point(P, pp.sx[i], pp.sy[i], pp.sz[i], s0, s1, s2);
+        const int j = m.idx;
+        const float d0 = pp.tx[j], d1 = pp.ty[j], d2 = pp.tz[j];
+        if (!(finite3(s0, s1, s2) && finite3(d0, d1, d2))) continue;
+        xform_normal(N, pp.snx[i], pp.sny[i], pp.snz[i], ns0, ns1, ns2);
+        const float n0 = pp.tnx[j] + ns0, n1 = pp.tny[j] + ns1, n2 = pp.tnz[j] + ns2;    // :809
+        accumulate_rows(1, s0 - ms0, s1 - ms1, s2 - ms2, d0 - md0, d1 - md1, d2 - md2, n0, n1, n2, m.weight, acc);
+    }
+    block_reduce<27>(acc, lds);
+    if (threadIdx.x == 0) {
+        double* o = pp.partials + (size_t)blockIdx.x * NSUM + SUM_M;
+#pragma unroll
+        for (int a = 0; a < 27; a++) o[a] = acc[a];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp64 small dense solvers, run by one thread of k_reduce_solve.
+__device__ inline void jacobi_eig_sym(double* A /* n x n, destroyed */, int n, double* V, double* ev) {
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 50; sweep++) {
+        double off = 0.0, dg = 0.0;
+        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) { if (i != j) off += A[i * n + j] * A[i * n + j]; else dg += A[i * n + j] * A[i * n + j]; }
+        if (off <= 1e-300 || off <= 1e-34 * dg) break;
+        for (int p = 0; p < n - 1; p++) for (int q = p + 1; q < n; q++) {
+            const double apq = A[p * n + q];
+            if (apq == 0.0) continue;
+            const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            for (int k = 0; k < n; k++) { const double akp = A[k * n + p], akq = A[k * n + q]; A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq; }
+            for (int k = 0; k < n; k++) { const double apk = A[p * n + k], aqk = A[q * n + k]; A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk; }
+            for (int k = 0; k < n; k++) { const double vkp = V[k * n + p], vkq = V[k * n + q]; V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq; }
+        }
+    }
+    for (int i = 0; i < n; i++) ev[i] = A[i * n + i];
+}
+
+// Minimum-norm least-squares solution from the normal equations with JacobiSVD::solve's rank rule
+// (singular values <= 6*eps_f32*sigma_max dropped, ICPOptimizer.h:757-758).
+__device__ inline void solve_normal_svd(const double* sums /* 21 + 6 */, double* x) {
+    double A[36], V[36], ev[6];
+    int q = 0;
+    for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { A[a * 6 + c] = sums[q]; A[c * 6 + a] = sums[q]; q++; }
+    const double* g = sums + 21;
+    jacobi_eig_sym(A, 6, V, ev);
+    double emax = 0.0;
+    for (int i = 0; i < 6; i++) emax = fmax(emax, ev[i]);
+    const double thr = 6.0 * 1.1920928955078125e-07;
+    for (int i = 0; i < 6; i++) x[i] = 0.0;
+    for (int j = 0; j < 6; j++) {
+        if (!(ev[j] > thr * thr * emax)) continue;
+        double vg = 0.0;
+        for (int i = 0; i < 6; i++) vg += V[i * 6 + j] * g[i];
+        const double coef = vg / ev[j];
+        for (int i = 0; i < 6; i++) x[i] += V[i * 6 + j] * coef;
+    }
+}
+
+// FullPivLU::solve with its rank rule in fp64 (ICPOptimizer.h:866-868).
+__device__ inline void solve_fullpiv_lu6(double* M, double* rhs, double* x) {
+    const int n = 6;
+    int colp[6];
+    for (int i = 0; i < n; i++) colp[i] = i;
+    double maxpiv = 0.0; int rank = n;
+    for (int k = 0; k < n; k++) {
+        int pr = k, pc = k; double best = -1.0;
+        for (int i = k; i < n; i++) for (int j = k; j < n; j++) { const double v = fabs(M[i * n + j]); if (v > best) { best = v; pr = i; pc = j; } }
+        if (best > maxpiv) maxpiv = best;
+        if (best == 0.0) { rank = k; break; }
+        if (pr != k) { for (int j = 0; j < n; j++) { const double t = M[k * n + j]; M[k * n + j] = M[pr * n + j]; M[pr * n + j] = t; } const double t = rhs[k]; rhs[k] = rhs[pr]; rhs[pr] = t; }
+        if (pc != k) { for (int i = 0; i < n; i++) { const double t = M[i * n + k]; M[i * n + k] = M[i * n + pc]; M[i * n + pc] = t; } const int t = colp[k]; colp[k] = colp[pc]; colp[pc] = t; }
+        for (int i = k + 1; i < n; i++) {
+            const double f = M[i * n + k] / M[k * n + k];
+            for (int j = k + 1; j < n; j++) M[i * n + j] -= f * M[k * n + j];
+            rhs[i] -= f * rhs[k];
+        }
+    }
+    const double thr = 1.1920928955078125e-07 * 6.0;
+    int r = 0;
+    for (int k = 0; k < rank; k++) { if (fabs(M[k * n + k]) > maxpiv * thr) r++; else break; }
+    double y[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = r - 1; k >= 0; k--) { double s = rhs[k]; for (int j = k + 1; j < r; j++) s -= M[k * n + j] * y[j]; y[k] = s / M[k * n + k]; }
+    for (int k = 0; k < n; k++) x[colp[k]] = (k < r) ? y[k] : 0.0;
+}
+
+// Rotation of the weighted Procrustes problem: R = U diag(1,1,det(UV^T)) V^T of A = U S V^T
+// (ProcrustesAligner.h:55-64).  V from the fp64 eigen-decomposition of A^T A (descending), U_c = A v_c/|A v_c|
+// for the two leading columns.  With c = U_0 x U_1 the reference's product collapses to
+//   R = U_0 V_0^T + U_1 V_1^T + det(V) * c * V_2^T
+// (flipping the sign of the third left vector flips det(UV^T) too), which stays well defined when sigma_3 -> 0.
+__device__ inline void procrustes_rotation(const double* A /* 3x3 row-major */, double* R) {
+    double B[9], V[9], ev[3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += A[k * 3 + i] * A[k * 3 + j]; B[i * 3 + j] = s; }
+    jacobi_eig_sym(B, 3, V, ev);
+    int o[3] = {0, 1, 2};
+    for (int a = 0; a < 2; a++) for (int b = a + 1; b < 3; b++) if (ev[o[b]] > ev[o[a]]) { const int t = o[a]; o[a] = o[b]; o[b] = t; }
+    double Vs[9], U[9];
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) Vs[r * 3 + c] = V[r * 3 + o[c]];
+    const double s0 = sqrt(fmax(ev[o[0]], 0.0));
+    for (int c = 0; c < 2; c++) {
+        double u[3];
+        for (int r = 0; r < 3; r++) { u[r] = 0; for (int k = 0; k < 3; k++) u[r] += A[r * 3 + k] * Vs[k * 3 + c]; }
+        if (c == 1) {   // re-orthogonalise against column 0 (exact in exact arithmetic)
+            const double dp = u[0] * U[0] + u[1] * U[3] + u[2] * U[6];
+            u[0] -= dp * U[0]; u[1] -= dp * U[3]; u[2] -= dp * U[6];
+        }
+        double nr = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        if (!(nr > 1e-13 * s0) || !(nr > 0.0)) {   // rank-deficient A: any unit vector orthogonal to what we have
+            if (c == 0) { u[0] = 1; u[1] = 0; u[2] = 0; }
+            else {
+                const double a0 = U[0], a1 = U[3], a2 = U[6];
+                const int kmin = fabs(a0) < fabs(a1) ? (fabs(a0) < fabs(a2) ? 0 : 2) : (fabs(a1) < fabs(a2) ? 1 : 2);
+                const double dp = (kmin == 0 ? a0 : (kmin == 1 ? a1 : a2));
+                u[0] = (kmin == 0 ? 1.0 : 0.0) - dp * a0; u[1] = (kmin == 1 ? 1.0 : 0.0) - dp * a1; u[2] = (kmin == 2 ? 1.0 : 0.0) - dp * a2;
+            }
+            nr = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        }
+        for (int r = 0; r < 3; r++) U[r * 3 + c] = u[r] / nr;
+    }
+    U[2] = U[3] * U[7] - U[6] * U[4]; U[5] = U[6] * U[1] - U[0] * U[7]; U[8] = U[0] * U[4] - U[3] * U[1];
+    const double detV = Vs[0] * (Vs[4] * Vs[8] - Vs[5] * Vs[7]) - Vs[1] * (Vs[3] * Vs[8] - Vs[5] * Vs[6]) + Vs[2] * (Vs[3] * Vs[7] - Vs[4] * Vs[6]);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+        R[r * 3 + c] = (U[r * 3] * Vs[c * 3] + U[r * 3 + 1] * Vs[c * 3 + 1]) + detV * U[r * 3 + 2] * Vs[c * 3 + 2];
+}
+
+// fp32 helpers with the Eigen fixed-size evaluation orders used by the reference's pose algebra
+__device__ inline void mat4_mul_f32(const float* A, const float* B, float* C) {   // column-major, sequential over k
+    float T[16];
+    for (int c = 0; c < 4; c++) for (int r = 0; r < 4; r++) {
+        float acc = A[0 * 4 + r] * B[c * 4 + 0];
+        acc = acc + A[1 * 4 + r] * B[c * 4 + 1];
+        acc = acc + A[2 * 4 + r] * B[c * 4 + 2];
+        acc = acc + A[3 * 4 + r] * B[c * 4 + 3];
+        T[c * 4 + r] = acc;
+    }
+    for (int i = 0; i < 16; i++) C[i] = T[i];
+}
+__device__ inline void mat3_mul_f32(const float* A, const float* B, float* C) {   // row-major, e0 + (e1 + e2)
+    float T[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) T[r * 3 + c] = A[r * 3] * B[c] + (A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c]);
+    for (int i = 0; i < 9; i++) C[i] = T[i];
+}
+__device__ inline void set_pose_f32(float* pose, const float* R, const float* t) {
+    for (int i = 0; i < 16; i++) pose[i] = (i % 5 == 0) ? 1.f : 0.f;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) pose[c * 4 + r] = R[r * 3 + c]; pose[12 + r] = t[r]; }
+}
+// (R^-1)^T by fp64 cofactors rounded once (same operation order as the oracle's normal_matrix)
+__device__ __host__ inline void normal_matrix_from_pose(const float* pose, float* N) {
+    const double a = pose[0], b = pose[4], c = pose[8];
+    const double d = pose[1], e = pose[5], f = pose[9];
+    const double g = pose[2], h = pose[6], i = pose[10];
+    const double c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
+    const double c10 = c * h - b * i, c11 = a * i - c * g, c12 = b * g - a * h;
+    const double c20 = b * f - c * e, c21 = c * d - a * f, c22 = a * e - b * d;
+    const double det = (a * c00 + b * c01) + c * c02;
+    N[0] = (float)(c00 / det); N[1] = (float)(c01 / det); N[2] = (float)(c02 / det);
+    N[3] = (float)(c10 / det); N[4] = (float)(c11 / det); N[5] = (float)(c12 / det);
+    N[6] = (float)(c20 / det); N[7] = (float)(c21 / det); N[8] = (float)(c22 / det);
+}
+
+struct SolveParams {
+    const double* partials; int nblocks;
+    PoseState* ps;
+    int metric; int phase;         // phase 0: full solve (p2p / p2plane) or means only (symmetric); phase 1: symmetric solve
+    icp_iter_stats* stats;         // record slot of this iteration (may be null)
+    int n_src;
+    double* sums_out;              // optional copy of the reduced sums (NSUM doubles)
+    int update_pose;               // 0: only reduce (icp_correspond)
+    const double* rmse_partials; int rmse_blocks;   // unused here
+};
+
+__global__ __launch_bounds__(256) void k_reduce_solve(const SolveParams sp) {
+    __shared__ double tot[NSUM];
+    // fixed-order reduction of the block partials: wave w owns sums w, w+4, ...; lanes stride the
+    // blocks sequentially, then a shuffle tree -- identical order on every run.
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int a = w; a < NSUM; a += 4) {
+        double x = 0.0;
+        for (int b = lane; b < sp.nblocks; b += WAVE) x += sp.partials[(size_t)b * NSUM + a];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
+        if (lane == 0) tot[a] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (sp.sums_out) for (int a = 0; a < NSUM; a++) sp.sums_out[a] = tot[a];
+    PoseState* ps = sp.ps;
+    const double n = tot[SUM_N];
+    if (sp.phase == 0) {
+        // means of the valid pairs (utils.h:136-145 computes them as fp32 running sums; here fp64 sums rounded once)
+        float ms[3] = {0, 0, 0}, md[3] = {0, 0, 0};
+        if (n > 0) for (int k = 0; k < 3; k++) { ms[k] = (float)(tot[SUM_S + k] / n); md[k] = (float)(tot[SUM_D + k] / n); }
+        for (int k = 0; k < 3; k++) { ps->mean_s[k] = ms[k]; ps->mean_d[k] = md[k]; }
+    }
+    if (!sp.update_pose) return;
+    if (sp.metric == ICP_METRIC_SYMMETRIC && sp.phase == 0) return;      // wait for the second pass
+    int status = ICP_OK;
+    float dT[16];
+    for (int i = 0; i < 16; i++) dT[i] = (i % 5 == 0) ? 1.f : 0.f;
+    if (!(n > 0)) {
+        status = ICP_ERR_NO_CORRESPONDENCES;
+    } else if (sp.metric == ICP_METRIC_POINT_TO_PLANE) {
+        double x[6];
+        solve_normal_svd(tot + SUM_M, x);
+        const float al = (float)x[0], be = (float)x[1], ga = (float)x[2];       // ICPOptimizer.h:768
+        const float ca = (float)cos((double)al), sa = (float)sin((double)al);
+        const float cb = (float)cos((double)be), sb = (float)sin((double)be);
+        const float cg = (float)cos((double)ga), sg = (float)sin((double)ga);
+        const float Rx[9] = {1, 0, 0, 0, ca, -sa, 0, sa, ca}, Ry[9] = {cb, 0, sb, 0, 1, 0, -sb, 0, cb}, Rz[9] = {cg, -sg, 0, sg, cg, 0, 0, 0, 1};
+        float Rxy[9], R[9];
+        mat3_mul_f32(Rx, Ry, Rxy); mat3_mul_f32(Rxy, Rz, R);                   // :771-773
+        const float t[3] = {(float)x[3], (float)x[4], (float)x[5]};
+        set_pose_f32(dT, R, t);
+    } else if (sp.metric == ICP_METRIC_POINT_TO_POINT) {
+        // A = sum_i (d_i - dm)(w_i (s_i - sm))^T expanded in moments (ProcrustesAligner.h:50-55)
+        const double* m = tot + SUM_M;
+        const float msf[3] = {ps->mean_s[0], ps->mean_s[1], ps->mean_s[2]}, mdf[3] = {ps->mean_d[0], ps->mean_d[1], ps->mean_d[2]};
+        double A[9];
+        for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++)
+            A[j * 3 + k] = m[7 + j * 3 + k] - m[4 + j] * (double)msf[k] - (double)mdf[j] * m[1 + k] + m[0] * (double)mdf[j] * (double)msf[k];
+        double Rd[9]; float R[9];
+        procrustes_rotation(A, Rd);
+        for (int i = 0; i < 9; i++) R[i] = (float)Rd[i];
+        const float tr[3] = {mdf[0] - msf[0], mdf[1] - msf[1], mdf[2] - msf[2]};     // ProcrustesAligner.h:70
+        float t[3];
+        for (int r = 0; r < 3; r++) {
+            const float Rt = R[r * 3] * tr[0] + (R[r * 3 + 1] * tr[1] + R[r * 3 + 2] * tr[2]);
+            const float Rm = R[r * 3] * mdf[0] + (R[r * 3 + 1] * mdf[1] + R[r * 3 + 2] * mdf[2]);
+            t[r] = (Rt - Rm) + mdf[r];                                             // ProcrustesAligner.h:26
+        }
+        set_pose_f32(dT, R, t);
+    } else {
+        // symmetric: M = A^T A + lambda^2 I, FullPivLU (ICPOptimizer.h:858-868)
+        double M[36], g[6], x[6];
+        int q = 0;
+        for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { M[a * 6 + c] = tot[SUM_M + q]; M[c * 6 + a] = tot[SUM_M + q]; q++; }
+        for (int a = 0; a < 6; a++) g[a] = tot[SUM_M + 21 + a];
+        const float lambda = 0.0001f; const float l2 = lambda * lambda;
+        for (int a = 0; a < 6; a++) M[a * 6 + a] += (double)l2;
+        solve_fullpiv_lu6(M, g, x);
+        const float at[3] = {(float)x[0], (float)x[1], (float)x[2]}, tt[3] = {(float)x[3], (float)x[4], (float)x[5]};
+        const float tan_theta = sqrtf(at[0] * at[0] + (at[1] * at[1] + at[2] * at[2]));     // :878
+        const float ax[3] = {at[0] / tan_theta, at[1] / tan_theta, at[2] / tan_theta};      // :879
+        const float sin_theta = (float)((double)tan_theta / sqrt(1.0 + (double)(tan_theta * tan_theta)));   // :884
+        const float cos_theta = sin_theta / tan_theta;                                      // :885
+        const float t[3] = {tt[0] * cos_theta, tt[1] * cos_theta, tt[2] * cos_theta};
+        const float K[9] = {0, -ax[2], ax[1], ax[2], 0, -ax[0], -ax[1], ax[0], 0};
+        float Ks[9], KK[9], Rod[9];
+        const float omc = 1 - cos_theta;
+        for (int i = 0; i < 9; i++) Ks[i] = omc * K[i];
+        mat3_mul_f32(Ks, K, KK);
+        for (int i = 0; i < 9; i++) Rod[i] = ((i % 4 == 0) ? 1.f : 0.f) + (sin_theta * K[i] + KK[i]);   // utils.h:171-176
+        const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, zero[3] = {0, 0, 0};
+        const float md[3] = {ps->mean_d[0], ps->mean_d[1], ps->mean_d[2]}, nms[3] = {-ps->mean_s[0], -ps->mean_s[1], -ps->mean_s[2]};
+        float Tm[16], Tt[16], Ts[16], Rm[16], t1[16], t2[16];
+        set_pose_f32(Tm, I3, md); set_pose_f32(Tt, I3, t); set_pose_f32(Ts, I3, nms); set_pose_f32(Rm, Rod, zero);
+        mat4_mul_f32(Tm, Rm, t1); mat4_mul_f32(t1, Tt, t2); mat4_mul_f32(t2, Rm, t1); mat4_mul_f32(t1, Ts, dT);   // :894-895
+    }
+    if (status == ICP_OK) {
+        float np[16];
+        mat4_mul_f32(dT, ps->pose, np);                                           // ICPOptimizer.h:614-620
+        for (int i = 0; i < 16; i++) ps->pose[i] = np[i];
+        normal_matrix_from_pose(ps->pose, ps->nmat);
+    }
+    if (sp.stats) {
+        sp.stats->n_src = sp.n_src;
+        sp.stats->n_valid = (int)n;
+        for (int i = 0; i < 16; i++) sp.stats->pose[i] = ps->pose[i];
+        sp.stats->rmse = -1.f;
+        sp.stats->status = status;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ConvergenceMeasure::rmseAlignmentError (ConvergenceMeasure.h:50-66): sum of squared distances between
+// pose*src[i] and ref[i] over pairs where both are finite.  fp64 block partials {sum, count}.
+__global__ __launch_bounds__(256) void k_rmse_partial(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+                                                      const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
+                                                      int n, const PoseState* __restrict__ ps, double* __restrict__ partials) {
+    __shared__ double lds[4 * 2];
+    double acc[2] = {0.0, 0.0};
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+        float a, b, c;
+        xform_point(ps->pose, sx[k], sy[k], sz[k], a, b, c);
+        const float r0 = rx[k], r1 = ry[k], r2 = rz[k];
+        if (finite3(a, b, c) && finite3(r0, r1, r2)) {
+            const float e0 = a - r0, e1 = b - r1, e2 = c - r2;
+            acc[0] += (double)(e0 * e0 + (e1 * e1 + e2 * e2));
+            acc[1] += 1.0;
+        }
+    }
+    block_reduce<2>(acc, lds);
+    if (threadIdx.x == 0) { partials[blockIdx.x * 2] = acc[0]; partials[blockIdx.x * 2 + 1] = acc[1]; }
+}
+__global__ void k_rmse_finish(const double* __restrict__ partials, int nblocks, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0, c = 0.0;
+    for (int b = 0; b < nblocks; b++) { s += partials[b * 2]; c += partials[b * 2 + 1]; }
+    *out = (float)sqrt(s / c);
+}
+
+// utils.h:106-133 as stand-alone kernels for the adaptor's transformPoints / transformNormals
+__global__ void k_transform_aos(const float* __restrict__ in, int n, const PoseState* __restrict__ ps, int normals, float* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float x = in[(size_t)k * 3], y = in[(size_t)k * 3 + 1], z = in[(size_t)k * 3 + 2];
+    float a, b, c;
+    if (normals) xform_normal(ps->nmat, x, y, z, a, b, c); else xform_point(ps->pose, x, y, z, a, b, c);
+    out[(size_t)k * 3] = a; out[(size_t)k * 3 + 1] = b; out[(size_t)k * 3 + 2] = c;
+}
+
+}  // namespace icpdev

@@ -1,0 +1,564 @@
+// =====================================================================================
+// icp_hip.hip -- C-ABI implementation (libicp_hip.so) over the gfx950 kernels in icp_device.hpp.
+// Entry points and the reference interfaces they replace are documented in include/icp_hip.h.
+// There is NO CPU fallback: every entry point needs a HIP device and fails with ICP_ERR_HIP /
+// ICP_ERR_NO_DEVICE when none is usable.
+// =====================================================================================
+#include "icp_device.hpp"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace icpdev;
+
+#define HIPCK(ctx, expr)                                                                        \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            char buf__[256];                                                                    \
+            snprintf(buf__, sizeof(buf__), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            (ctx)->err = buf__;                                                                 \
+            return ICP_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    template <class T> T* as() const { return (T*)p; }
+};
+
+struct Cloud {
+    int n = 0, npad = 0;
+    DevBuf x, y, z, nx, ny, nz, cr, cg, cb, rgba;
+    bool has_normals = false, has_colors = false;
+};
+
+struct Level { DevBuf idx; int n = 0; };
+
+}  // namespace
+
+struct icp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    icp_params prm;
+    Cloud tgt, src, qry;                 // qry: scratch cloud of icp_query_matches
+    std::vector<uint8_t> src_valid;      // host mask: finite point && finite normal (PointCloud.h:334)
+    std::map<int, Level> levels;         // multires selections by decimation factor
+    DevBuf ps, matches, d2, best64, partials, sums, stats, staging, rmse_partials, rmse_out;
+    Cloud conv_src, conv_ref; int conv_n = 0;
+    float cos_reject = 0.5f;
+    std::vector<hipEvent_t> events;
+    icp_timing timing;
+    std::string err;
+};
+
+namespace {
+
+constexpr int POST_BLOCKS = 512;
+
+int ensure(icp_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return ICP_OK;
+    if (b.p) { HIPCK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes < 256 ? 256 : bytes;
+    HIPCK(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return ICP_OK;
+}
+void release(DevBuf& b) { if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; } }
+void release(Cloud& c) { release(c.x); release(c.y); release(c.z); release(c.nx); release(c.ny); release(c.nz); release(c.cr); release(c.cg); release(c.cb); release(c.rgba); }
+
+// Largest float c with (double)acosf(c) > 60*pi/180 on THIS host's libm: the device rejection test
+// `c <= cos_reject` is then bit-identical to the reference's `acos(c) > threshold` (ICPOptimizer.h:161,170)
+// as evaluated by the host the reference would run on (acosf is monotone on [0.25, 0.75]).
+float compute_cos_reject() {
+    const double threshold = 60 * 3.141592653589793238462643383279502884 / 180.0;
+    uint32_t lo, hi; float flo = 0.25f, fhi = 0.75f;
+    memcpy(&lo, &flo, 4); memcpy(&hi, &fhi, 4);       // predicate true at lo, false at hi
+    while (hi - lo > 1) {
+        uint32_t mid = lo + (hi - lo) / 2; float fm; memcpy(&fm, &mid, 4);
+        if ((double)acosf(fm) > threshold) lo = mid; else hi = mid;
+    }
+    float r; memcpy(&r, &lo, 4);
+    return r;
+}
+
+int set_device(icp_ctx* c) { HIPCK(c, hipSetDevice(c->device)); return ICP_OK; }
+
+// Host AoS -> device SoA (+ optional padding with pad_value).
+int upload3(icp_ctx* c, const float* aos, int n, int npad, float pad_value, DevBuf& x, DevBuf& y, DevBuf& z) {
+    int rc;
+    if ((rc = ensure(c, c->staging, (size_t)n * 12))) return rc;
+    if ((rc = ensure(c, x, (size_t)npad * 4))) return rc;
+    if ((rc = ensure(c, y, (size_t)npad * 4))) return rc;
+    if ((rc = ensure(c, z, (size_t)npad * 4))) return rc;
+    HIPCK(c, hipMemcpyAsync(c->staging.p, aos, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_deinterleave3, dim3((npad + 255) / 256), dim3(256), 0, c->stream, c->staging.as<float>(), n, npad, pad_value,
+                       x.as<float>(), y.as<float>(), z.as<float>());
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipStreamSynchronize(c->stream));      // staging is reused by the next upload
+    return ICP_OK;
+}
+int upload_colors(icp_ctx* c, const uint8_t* rgba, int n, int npad, Cloud& cl) {
+    int rc;
+    if ((rc = ensure(c, c->staging, (size_t)n * 4))) return rc;
+    if ((rc = ensure(c, cl.rgba, (size_t)npad * 4))) return rc;
+    if ((rc = ensure(c, cl.cr, (size_t)npad * 4))) return rc;
+    if ((rc = ensure(c, cl.cg, (size_t)npad * 4))) return rc;
+    if ((rc = ensure(c, cl.cb, (size_t)npad * 4))) return rc;
+    HIPCK(c, hipMemcpyAsync(c->staging.p, rgba, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_colors, dim3((npad + 255) / 256), dim3(256), 0, c->stream, c->staging.as<uint8_t>(), n, npad,
+                       cl.rgba.as<uint32_t>(), cl.cr.as<float>(), cl.cg.as<float>(), cl.cb.as<float>());
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return ICP_OK;
+}
+
+int upload_cloud(icp_ctx* c, Cloud& cl, const float* xyz, const float* nrm, const uint8_t* rgba, int n, bool pad_inf) {
+    const int npad = pad_inf ? ((n + 63) / 64) * 64 : n;
+    int rc;
+    if ((rc = upload3(c, xyz, n, npad, INFINITY, cl.x, cl.y, cl.z))) return rc;
+    cl.has_normals = nrm != nullptr;
+    if (nrm && (rc = upload3(c, nrm, n, n, 0.f, cl.nx, cl.ny, cl.nz))) return rc;
+    cl.has_colors = rgba != nullptr;
+    if (rgba && (rc = upload_colors(c, rgba, n, npad, cl))) return rc;
+    cl.n = n; cl.npad = npad;
+    return ICP_OK;
+}
+
+int write_pose(icp_ctx* c, const float pose[16]) {
+    PoseState h; memset(&h, 0, sizeof(h));
+    memcpy(h.pose, pose, 64);
+    normal_matrix_from_pose(h.pose, h.nmat);
+    int rc;
+    if ((rc = ensure(c, c->ps, sizeof(PoseState)))) return rc;
+    HIPCK(c, hipMemcpyAsync(c->ps.p, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));      // h is a stack object
+    return ICP_OK;
+}
+
+struct QuerySet { const Cloud* cl; const int* sel; int n; int pretransformed; bool use_colors; };
+
+int ensure_match_buffers(icp_ctx* c, int n) {
+    int rc;
+    if ((rc = ensure(c, c->matches, (size_t)n * sizeof(icp_match_t)))) return rc;
+    if ((rc = ensure(c, c->d2, (size_t)n * 4))) return rc;
+    return ICP_OK;
+}
+
+// Enqueue the matching stage (no sync).
+int launch_match(icp_ctx* c, const QuerySet& q) {
+    const icp_params& p = c->prm;
+    int rc;
+    if ((rc = ensure_match_buffers(c, q.n))) return rc;
+    if (p.matching == ICP_MATCH_PROJECTIVE) {
+        ProjParams pp;
+        pp.sx = q.cl->x.as<float>(); pp.sy = q.cl->y.as<float>(); pp.sz = q.cl->z.as<float>(); pp.sel = q.sel; pp.n = q.n;
+        pp.tx = c->tgt.x.as<float>(); pp.ty = c->tgt.y.as<float>(); pp.tz = c->tgt.z.as<float>();
+        pp.width = p.width; pp.height = p.height; pp.fx = p.fx; pp.fy = p.fy; pp.mx = p.cx; pp.my = p.cy; pp.window = 12;   // NearestNeighbor.h:319
+        pp.ps = c->ps.as<PoseState>(); pp.pretransformed = q.pretransformed; pp.max_dist = p.max_distance;
+        pp.out = c->matches.as<icp_match_t>(); pp.d2_out = c->d2.as<float>();
+        hipLaunchKernelGGL(k_projective, dim3((q.n + 255) / 256), dim3(256), 0, c->stream, pp);
+        HIPCK(c, hipGetLastError());
+        return ICP_OK;
+    }
+    KnnParams kp;
+    kp.sx = q.cl->x.as<float>(); kp.sy = q.cl->y.as<float>(); kp.sz = q.cl->z.as<float>();
+    kp.scr = q.cl->cr.as<float>(); kp.scg = q.cl->cg.as<float>(); kp.scb = q.cl->cb.as<float>();
+    kp.sel = q.sel; kp.n = q.n;
+    kp.tx = c->tgt.x.as<float>(); kp.ty = c->tgt.y.as<float>(); kp.tz = c->tgt.z.as<float>();
+    kp.tcr = c->tgt.cr.as<float>(); kp.tcg = c->tgt.cg.as<float>(); kp.tcb = c->tgt.cb.as<float>();
+    kp.mpad = c->tgt.npad; kp.ps = c->ps.as<PoseState>(); kp.pretransformed = q.pretransformed; kp.max_dist = p.max_distance;
+    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr;
+    const int bx = (q.n + WAVE - 1) / WAVE;
+    const int nch = kp.mpad / KNN_CH;
+    int nseg = 1;
+    if (bx < 1024) { nseg = (2048 + bx - 1) / bx; if (nseg > nch / 4) nseg = nch / 4; if (nseg < 1) nseg = 1; }
+    kp.nseg = nseg;
+    if (nseg > 1) {
+        if ((rc = ensure(c, c->best64, (size_t)q.n * 8))) return rc;
+        kp.best64 = c->best64.as<unsigned long long>();
+        const unsigned long long init = ((unsigned long long)0x7F7FFFFFu << 32) | 0xFFFFFFFFull;   // (FLT_MAX, idx -1)
+        hipLaunchKernelGGL(k_fill_u64, dim3((q.n + 255) / 256), dim3(256), 0, c->stream, kp.best64, q.n, init);
+    }
+    if (q.use_colors) hipLaunchKernelGGL(k_knn_brute<6>, dim3(bx, nseg), dim3(256), 0, c->stream, kp);
+    else              hipLaunchKernelGGL(k_knn_brute<3>, dim3(bx, nseg), dim3(256), 0, c->stream, kp);
+    if (nseg > 1)
+        hipLaunchKernelGGL(k_knn_finalize, dim3((q.n + 255) / 256), dim3(256), 0, c->stream, kp.best64, q.n, p.max_distance,
+                           c->matches.as<icp_match_t>(), c->d2.as<float>());
+    HIPCK(c, hipGetLastError());
+    return ICP_OK;
+}
+
+// Enqueue weight + reject + accumulate (+ symmetric second pass) + reduce/solve (no sync).
+int launch_post_and_solve(icp_ctx* c, const int* sel, int n, icp_iter_stats* d_stats, double* d_sums_out, int update_pose,
+                          hipEvent_t ev_after_post) {
+    const icp_params& p = c->prm;
+    int rc;
+    if ((rc = ensure(c, c->partials, (size_t)POST_BLOCKS * NSUM * 8))) return rc;
+    PostParams pp;
+    pp.sx = c->src.x.as<float>(); pp.sy = c->src.y.as<float>(); pp.sz = c->src.z.as<float>();
+    pp.snx = c->src.nx.as<float>(); pp.sny = c->src.ny.as<float>(); pp.snz = c->src.nz.as<float>();
+    pp.srgba = c->src.rgba.as<uint32_t>(); pp.sel = sel; pp.n = n;
+    pp.tx = c->tgt.x.as<float>(); pp.ty = c->tgt.y.as<float>(); pp.tz = c->tgt.z.as<float>();
+    pp.tnx = c->tgt.nx.as<float>(); pp.tny = c->tgt.ny.as<float>(); pp.tnz = c->tgt.nz.as<float>(); pp.trgba = c->tgt.rgba.as<uint32_t>();
+    pp.ps = c->ps.as<PoseState>(); pp.matches = c->matches.as<icp_match_t>();
+    pp.metric = p.metric; pp.weighting = p.weighting; pp.rejection = p.rejection;
+    pp.max_dist = p.max_distance; pp.cos_reject = c->cos_reject; pp.partials = c->partials.as<double>();
+    int nb = (n + POST_THREADS - 1) / POST_THREADS; if (nb > POST_BLOCKS) nb = POST_BLOCKS; if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_post, dim3(nb), dim3(POST_THREADS), 0, c->stream, pp);
+    SolveParams sp; memset(&sp, 0, sizeof(sp));
+    sp.partials = c->partials.as<double>(); sp.nblocks = nb; sp.ps = c->ps.as<PoseState>(); sp.metric = p.metric;
+    sp.n_src = n; sp.update_pose = update_pose;
+    if (p.metric == ICP_METRIC_SYMMETRIC) {
+        sp.phase = 0; sp.stats = nullptr; sp.sums_out = nullptr;
+        hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(256), 0, c->stream, sp);       // means
+        hipLaunchKernelGGL(k_sym_accumulate, dim3(nb), dim3(POST_THREADS), 0, c->stream, pp);
+        if (ev_after_post) HIPCK(c, hipEventRecord(ev_after_post, c->stream));
+        sp.phase = 1; sp.stats = d_stats; sp.sums_out = d_sums_out;
+        hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(256), 0, c->stream, sp);
+    } else {
+        if (ev_after_post) HIPCK(c, hipEventRecord(ev_after_post, c->stream));
+        sp.phase = 0; sp.stats = d_stats; sp.sums_out = d_sums_out;
+        hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(256), 0, c->stream, sp);
+    }
+    HIPCK(c, hipGetLastError());
+    return ICP_OK;
+}
+
+int check_ready(icp_ctx* c, bool need_source, bool full_pipeline) {
+    const icp_params& p = c->prm;
+    if (c->tgt.n <= 0) { c->err = "target index needs to be built before querying (icp_set_target)"; return ICP_ERR_NO_TARGET; }
+    if (need_source && c->src.n <= 0) { c->err = "no source cloud (icp_set_source)"; return ICP_ERR_NO_SOURCE; }
+    if (p.matching == ICP_MATCH_PROJECTIVE) {
+        if (p.height <= 0 || p.width <= 0) { c->err = "set camera params before querying any matches"; return ICP_ERR_NO_CAMERA; }
+        if ((long long)p.width * p.height != c->tgt.n) { c->err = "invalid size of target points (must be width*height)"; return ICP_ERR_TARGET_SIZE; }
+    } else if (p.color_icp) {
+        if (!c->tgt.has_colors || (need_source && !c->src.has_colors)) { c->err = "colour ICP needs colours on target and source"; return ICP_ERR_COLOR_MISMATCH; }
+    }
+    if (full_pipeline) {
+        if (!c->tgt.has_normals || !c->src.has_normals) { c->err = "normals required on source and target"; return ICP_ERR_INVALID_ARG; }
+        if (p.weighting == ICP_WEIGHT_COLORS && (!c->tgt.has_colors || !c->src.has_colors)) { c->err = "colour weighting needs colours"; return ICP_ERR_COLOR_MISMATCH; }
+    }
+    return ICP_OK;
+}
+
+// Selection for a decimation factor: PointCloud::getCoarseResolution (PointCloud.h:325-343).
+int get_level(icp_ctx* c, int factor, const int** d_idx, int* n_out) {
+    auto it = c->levels.find(factor);
+    if (it == c->levels.end()) {
+        std::vector<int> idx;
+        idx.reserve(c->src.n / factor + 1);
+        for (int i = 0; i < c->src.n; i += factor) if (c->src_valid[i]) idx.push_back(i);
+        Level lv; lv.n = (int)idx.size();
+        int rc;
+        if ((rc = ensure(c, lv.idx, (size_t)(lv.n > 0 ? lv.n : 1) * 4))) return rc;
+        if (lv.n > 0) HIPCK(c, hipMemcpy(lv.idx.p, idx.data(), (size_t)lv.n * 4, hipMemcpyHostToDevice));
+        it = c->levels.emplace(factor, lv).first;
+    }
+    *d_idx = it->second.idx.as<int>(); *n_out = it->second.n;
+    return ICP_OK;
+}
+
+int ensure_events(icp_ctx* c, size_t count) {
+    while (c->events.size() < count) { hipEvent_t e; HIPCK(c, hipEventCreate(&e)); c->events.push_back(e); }
+    return ICP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* icp_version(void) { return "icp_hip gfx950 r1"; }
+
+int icp_params_default(icp_params* p) {
+    if (!p) return ICP_ERR_INVALID_ARG;
+    memset(p, 0, sizeof(*p));
+    p->metric = 0; p->matching = 0; p->weighting = 0; p->rejection = 1; p->color_icp = 0; p->multires = 0;   // ICPOptimizer.h:29-31
+    p->n_iterations = 20; p->max_distance = 0.0003f;
+    p->knn_backend = ICP_KNN_BRUTE_FORCE; p->record_rmse = 0;
+    return ICP_OK;
+}
+
+int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out) {
+    if (!out) return ICP_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ICP_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return ICP_ERR_INVALID_ARG;
+    icp_ctx* c = new icp_ctx();
+    c->device = device;
+    icp_params_default(&c->prm);
+    memset(&c->timing, 0, sizeof(c->timing));
+    if (hipSetDevice(device) != hipSuccess) { delete c; return ICP_ERR_HIP; }
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->owns_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ICP_ERR_HIP; }
+        c->owns_stream = true;
+    }
+    c->cos_reject = compute_cos_reject();
+    float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    int rc = write_pose(c, ident);
+    if (rc) { icp_ctx_destroy(c); return rc; }
+    *out = c;
+    return ICP_OK;
+}
+int icp_ctx_create(int device, icp_ctx** out) { return icp_ctx_create_on_stream(device, nullptr, out); }
+
+int icp_ctx_destroy(icp_ctx* c) {
+    if (!c) return ICP_ERR_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    release(c->tgt); release(c->src); release(c->qry); release(c->conv_src); release(c->conv_ref);
+    for (auto& kv : c->levels) release(kv.second.idx);
+    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->partials); release(c->sums);
+    release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out);
+    for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return ICP_OK;
+}
+
+const char* icp_last_error(const icp_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int icp_set_params(icp_ctx* c, const icp_params* p) {
+    if (!c || !p) return ICP_ERR_INVALID_ARG;
+    if (p->metric < 0 || p->metric > 2 || p->matching < 0 || p->matching > 1 || p->weighting < 0 || p->weighting > 3 || p->n_iterations < 0) {
+        c->err = "icp_set_params: value out of range"; return ICP_ERR_INVALID_ARG;
+    }
+    c->prm = *p;
+    return ICP_OK;
+}
+int icp_get_params(const icp_ctx* c, icp_params* p) { if (!c || !p) return ICP_ERR_INVALID_ARG; *p = c->prm; return ICP_OK; }
+
+int icp_set_target(icp_ctx* c, const float* xyz, const float* normals, const uint8_t* rgba, int32_t n) {
+    if (!c || !xyz || n <= 0) { if (c) c->err = "icp_set_target: null points or n <= 0"; return ICP_ERR_INVALID_ARG; }
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    return upload_cloud(c, c->tgt, xyz, normals, rgba, n, true);
+}
+
+int icp_set_source(icp_ctx* c, const float* xyz, const float* normals, const uint8_t* rgba, int32_t n) {
+    if (!c || !xyz || n <= 0) { if (c) c->err = "icp_set_source: null points or n <= 0"; return ICP_ERR_INVALID_ARG; }
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = upload_cloud(c, c->src, xyz, normals, rgba, n, false))) return rc;
+    c->src_valid.assign((size_t)n, 0);
+    for (int i = 0; i < n; i++) {
+        bool ok = std::isfinite(xyz[(size_t)i * 3]) && std::isfinite(xyz[(size_t)i * 3 + 1]) && std::isfinite(xyz[(size_t)i * 3 + 2]);
+        if (ok && normals) ok = std::isfinite(normals[(size_t)i * 3]) && std::isfinite(normals[(size_t)i * 3 + 1]) && std::isfinite(normals[(size_t)i * 3 + 2]);
+        c->src_valid[i] = ok ? 1 : 0;
+    }
+    for (auto& kv : c->levels) release(kv.second.idx);
+    c->levels.clear();
+    return ICP_OK;
+}
+
+int icp_query_matches(icp_ctx* c, const float* transformed_xyz, const uint8_t* rgba, int32_t n, icp_match_t* out) {
+    if (!c || !transformed_xyz || !out || n <= 0) { if (c) c->err = "icp_query_matches: bad argument"; return ICP_ERR_INVALID_ARG; }
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = check_ready(c, false, false))) return rc;
+    const bool colors = rgba != nullptr;
+    if (c->prm.matching == ICP_MATCH_KNN && colors && !c->tgt.has_colors) {      // NearestNeighbor.h:240-243
+        c->err = "index built without colours: call queryMatches without colours";
+        return ICP_ERR_COLOR_MISMATCH;
+    }
+    if ((rc = upload_cloud(c, c->qry, transformed_xyz, nullptr, rgba, n, false))) return rc;
+    QuerySet q{&c->qry, nullptr, n, 1, colors && c->prm.matching == ICP_MATCH_KNN};
+    if ((rc = launch_match(c, q))) return rc;
+    HIPCK(c, hipMemcpyAsync(out, c->matches.p, (size_t)n * sizeof(icp_match_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return ICP_OK;
+}
+
+int icp_match(icp_ctx* c, const float pose[16], icp_match_t* out, float* d2_out) {
+    if (!c || !pose || !out) { if (c) c->err = "icp_match_t: bad argument"; return ICP_ERR_INVALID_ARG; }
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = check_ready(c, true, false))) return rc;
+    if ((rc = write_pose(c, pose))) return rc;
+    QuerySet q{&c->src, nullptr, c->src.n, 0, c->prm.color_icp != 0 && c->prm.matching == ICP_MATCH_KNN};
+    if ((rc = launch_match(c, q))) return rc;
+    HIPCK(c, hipMemcpyAsync(out, c->matches.p, (size_t)q.n * sizeof(icp_match_t), hipMemcpyDeviceToHost, c->stream));
+    if (d2_out) HIPCK(c, hipMemcpyAsync(d2_out, c->d2.p, (size_t)q.n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return ICP_OK;
+}
+
+int icp_correspond(icp_ctx* c, const float pose[16], icp_match_t* out, double* sums_out, int32_t* n_valid_out) {
+    if (!c || !pose) { if (c) c->err = "icp_correspond: bad argument"; return ICP_ERR_INVALID_ARG; }
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = check_ready(c, true, true))) return rc;
+    if ((rc = write_pose(c, pose))) return rc;
+    QuerySet q{&c->src, nullptr, c->src.n, 0, c->prm.color_icp != 0 && c->prm.matching == ICP_MATCH_KNN};
+    if ((rc = launch_match(c, q))) return rc;
+    if ((rc = ensure(c, c->sums, NSUM * 8))) return rc;
+    if ((rc = launch_post_and_solve(c, nullptr, q.n, nullptr, c->sums.as<double>(), 0, nullptr))) return rc;
+    double hs[NSUM];
+    if (out) HIPCK(c, hipMemcpyAsync(out, c->matches.p, (size_t)q.n * sizeof(icp_match_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(hs, c->sums.p, NSUM * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (sums_out) { memset(sums_out, 0, 64 * 8); memcpy(sums_out, hs, NSUM * 8); }
+    if (n_valid_out) *n_valid_out = (int32_t)hs[SUM_N];
+    return ICP_OK;
+}
+
+// Iteration schedule of LinearICPOptimizer::estimatePose: ICPOptimizer.h:503-516 (coarsest level),
+// :540 (loop condition `i < nIter || multires`) and :634-655 (refinement).  Pure host logic.
+int icp_schedule(const icp_params* p, int32_t n_src, int32_t* factors_out, int32_t max_out, int32_t* count_out) {
+    if (!p || !count_out || n_src < 0) return ICP_ERR_INVALID_ARG;
+    int cnt = 0;
+    if (!p->multires) {
+        for (int i = 0; i < p->n_iterations; i++) { if (factors_out && cnt < max_out) factors_out[cnt] = 0; cnt++; }
+    } else {
+        if (p->n_iterations < 1) return ICP_ERR_INVALID_ARG;     // `i >= m_nIterations - 1` is unsigned in the reference: never true
+        float res = 1.0f; int osz = n_src;
+        while (1) { osz = (int)(osz / 2.0); if (osz < 100) break; res *= 2.0f; }      // MULTI_RESOLUTION_MINIMUM_POINTS :21
+        for (int i = 0;; ++i) {
+            if (factors_out && cnt < max_out) factors_out[cnt] = (int)res;
+            cnt++;
+            if (res == 1.0f && i >= p->n_iterations - 1) break;
+            if (res == 1.0f) continue;
+            res /= 2.0f; if (res < 1.0f) res = 1.0f;
+        }
+    }
+    *count_out = cnt;
+    return ICP_OK;
+}
+
+static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int32_t max_stats, int32_t* n_run, bool single) {
+    const icp_params& p = c->prm;
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = check_ready(c, true, true))) return rc;
+    std::vector<int> factors;          // decimation factor per iteration; 0 = no selection (full cloud)
+    if (single) factors.push_back(0);
+    else {
+        int32_t cnt = 0;
+        if ((rc = icp_schedule(&p, c->src.n, nullptr, 0, &cnt))) { c->err = "multires with n_iterations < 1 never terminates in the reference"; return rc; }
+        factors.resize((size_t)cnt);
+        if (cnt > 0) icp_schedule(&p, c->src.n, factors.data(), cnt, &cnt);
+    }
+    const int iters = (int)factors.size();
+    if (n_run) *n_run = 0;
+    if (iters == 0) return ICP_OK;
+    if ((rc = write_pose(c, pose_inout))) return rc;
+    if ((rc = ensure(c, c->stats, (size_t)iters * sizeof(icp_iter_stats)))) return rc;
+    HIPCK(c, hipMemsetAsync(c->stats.p, 0, (size_t)iters * sizeof(icp_iter_stats), c->stream));
+    if ((rc = ensure_events(c, (size_t)iters * 3 + 1))) return rc;
+    // resolve selections up front (uploads) so the loop itself is launch-only
+    std::vector<const int*> sels(iters, nullptr); std::vector<int> ns(iters, c->src.n);
+    for (int i = 0; i < iters; i++) if (factors[i] > 0) { if ((rc = get_level(c, factors[i], &sels[i], &ns[i]))) return rc; }
+    const bool rmse = p.record_rmse && c->conv_n > 0;
+    if (rmse) { if ((rc = ensure(c, c->rmse_partials, 256 * 2 * 8))) return rc; }
+    HIPCK(c, hipEventRecord(c->events[0], c->stream));
+    for (int i = 0; i < iters; i++) {
+        icp_iter_stats* d_st = c->stats.as<icp_iter_stats>() + i;
+        if (ns[i] > 0) {
+            QuerySet q{&c->src, sels[i], ns[i], 0, p.color_icp != 0 && p.matching == ICP_MATCH_KNN};
+            if ((rc = launch_match(c, q))) return rc;
+            HIPCK(c, hipEventRecord(c->events[1 + 3 * i], c->stream));
+            if ((rc = launch_post_and_solve(c, sels[i], ns[i], d_st, nullptr, 1, c->events[2 + 3 * i]))) return rc;
+        } else {
+            HIPCK(c, hipEventRecord(c->events[1 + 3 * i], c->stream));
+            HIPCK(c, hipEventRecord(c->events[2 + 3 * i], c->stream));
+        }
+        if (rmse) {
+            hipLaunchKernelGGL(k_rmse_partial, dim3(256), dim3(256), 0, c->stream, c->conv_src.x.as<float>(), c->conv_src.y.as<float>(), c->conv_src.z.as<float>(),
+                               c->conv_ref.x.as<float>(), c->conv_ref.y.as<float>(), c->conv_ref.z.as<float>(), c->conv_n, c->ps.as<PoseState>(), c->rmse_partials.as<double>());
+            hipLaunchKernelGGL(k_rmse_finish, dim3(1), dim3(64), 0, c->stream, c->rmse_partials.as<double>(), 256, &d_st->rmse);
+        }
+        HIPCK(c, hipEventRecord(c->events[3 + 3 * i], c->stream));
+    }
+    std::vector<icp_iter_stats> hs((size_t)iters);
+    PoseState hp;
+    HIPCK(c, hipMemcpyAsync(hs.data(), c->stats.p, (size_t)iters * sizeof(icp_iter_stats), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(&hp, c->ps.p, sizeof(hp), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    memcpy(pose_inout, hp.pose, 64);
+    int status = ICP_OK;
+    for (int i = 0; i < iters; i++) {
+        if (ns[i] <= 0) { hs[i].n_src = 0; hs[i].status = ICP_ERR_NO_CORRESPONDENCES; memcpy(hs[i].pose, i ? hs[i - 1].pose : pose_inout, 64); hs[i].rmse = -1.f; }
+        if (!rmse) hs[i].rmse = -1.f;
+        if (hs[i].status != ICP_OK && status == ICP_OK) status = hs[i].status;
+        if (stats && i < max_stats) stats[i] = hs[i];
+    }
+    if (n_run) *n_run = iters;
+    icp_timing& t = c->timing; memset(&t, 0, sizeof(t)); t.iterations = iters;
+    for (int i = 0; i < iters; i++) {
+        float a = 0, b = 0, d = 0;
+        HIPCK(c, hipEventElapsedTime(&a, c->events[3 * i], c->events[1 + 3 * i]));
+        HIPCK(c, hipEventElapsedTime(&b, c->events[1 + 3 * i], c->events[2 + 3 * i]));
+        HIPCK(c, hipEventElapsedTime(&d, c->events[2 + 3 * i], c->events[3 + 3 * i]));
+        t.match_ms += a; t.weight_reject_build_ms += b; t.solve_ms += d;
+    }
+    float tot = 0; HIPCK(c, hipEventElapsedTime(&tot, c->events[0], c->events[3 * iters])); t.total_ms = tot;
+    if (status != ICP_OK) c->err = "no valid correspondences in at least one iteration (reference would hang in ASSERT)";
+    return status;
+}
+
+int icp_iterate(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats) {
+    if (!c || !pose_inout) { if (c) c->err = "icp_iterate: bad argument"; return ICP_ERR_INVALID_ARG; }
+    int32_t n = 0;
+    return run_loop(c, pose_inout, stats, stats ? 1 : 0, &n, true);
+}
+
+int icp_run(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int32_t max_stats, int32_t* n_iterations_run) {
+    if (!c || !pose_inout) { if (c) c->err = "icp_run: bad argument"; return ICP_ERR_INVALID_ARG; }
+    return run_loop(c, pose_inout, stats, stats ? max_stats : 0, n_iterations_run, false);
+}
+
+int icp_get_timing(const icp_ctx* c, icp_timing* out) { if (!c || !out) return ICP_ERR_INVALID_ARG; *out = c->timing; return ICP_OK; }
+
+int icp_set_convergence_reference(icp_ctx* c, const float* src_xyz, const float* ref_xyz, int32_t n) {
+    if (!c || !src_xyz || !ref_xyz || n <= 0) { if (c) c->err = "icp_set_convergence_reference: bad argument"; return ICP_ERR_INVALID_ARG; }
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = upload3(c, src_xyz, n, n, 0.f, c->conv_src.x, c->conv_src.y, c->conv_src.z))) return rc;
+    if ((rc = upload3(c, ref_xyz, n, n, 0.f, c->conv_ref.x, c->conv_ref.y, c->conv_ref.z))) return rc;
+    c->conv_n = n;
+    return ICP_OK;
+}
+
+int icp_rmse(icp_ctx* c, const float pose[16], float* rmse_out) {
+    if (!c || !pose || !rmse_out) return ICP_ERR_INVALID_ARG;
+    if (c->conv_n <= 0) { c->err = "icp_rmse: no convergence reference set"; return ICP_ERR_INVALID_ARG; }
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = write_pose(c, pose))) return rc;
+    if ((rc = ensure(c, c->rmse_partials, 256 * 2 * 8))) return rc;
+    if ((rc = ensure(c, c->rmse_out, 4))) return rc;
+    hipLaunchKernelGGL(k_rmse_partial, dim3(256), dim3(256), 0, c->stream, c->conv_src.x.as<float>(), c->conv_src.y.as<float>(), c->conv_src.z.as<float>(),
+                       c->conv_ref.x.as<float>(), c->conv_ref.y.as<float>(), c->conv_ref.z.as<float>(), c->conv_n, c->ps.as<PoseState>(), c->rmse_partials.as<double>());
+    hipLaunchKernelGGL(k_rmse_finish, dim3(1), dim3(64), 0, c->stream, c->rmse_partials.as<double>(), 256, c->rmse_out.as<float>());
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(rmse_out, c->rmse_out.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return ICP_OK;
+}
+
+static int transform_common(icp_ctx* c, const float* in, int32_t n, const float pose[16], float* out, int normals) {
+    if (!c || !in || !out || !pose || n <= 0) { if (c) c->err = "icp_transform: bad argument"; return ICP_ERR_INVALID_ARG; }
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = write_pose(c, pose))) return rc;
+    if ((rc = ensure(c, c->staging, (size_t)n * 24))) return rc;
+    float* din = c->staging.as<float>(); float* dout = din + (size_t)n * 3;
+    HIPCK(c, hipMemcpyAsync(din, in, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_transform_aos, dim3((n + 255) / 256), dim3(256), 0, c->stream, din, n, c->ps.as<PoseState>(), normals, dout);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(out, dout, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return ICP_OK;
+}
+int icp_transform_points(icp_ctx* c, const float* xyz, int32_t n, const float pose[16], float* out) { return transform_common(c, xyz, n, pose, out, 0); }
+int icp_transform_normals(icp_ctx* c, const float* nrm, int32_t n, const float pose[16], float* out) { return transform_common(c, nrm, n, pose, out, 1); }
+
+}  // extern "C"

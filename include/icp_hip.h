@@ -1,0 +1,149 @@
+/* =====================================================================================
+ * icp_hip.h -- C ABI of the MI355X-native ICP hot path (libicp_hip.so)
+ *
+ * Drop-in boundary for the linear-ICP inner loop of PetropoulakisPanagiotis/ICP-Variants.
+ * The reference has no FFI; its "plugin surface" is three C++ interfaces resolved at compile
+ * time.  Each entry point below names the reference interface it replaces (file:line relative
+ * to icp-variants/ in the reference).  The C++14 adaptor classes that keep the reference's
+ * method names on top of this ABI are in include/icp_hip_adaptor.hpp; INTEGRATION.md shows the
+ * few lines a maintainer of the reference adds to switch over.
+ *
+ * Conventions (identical to the reference's containers, so no conversion is needed):
+ *   points / normals : N x 3 fp32, row-major, 12 B per element  == std::vector<Eigen::Vector3f>::data()
+ *   colours          : N x 4 uint8 RGBA                          == std::vector<Vector4uc>::data()   (Eigen.h:36)
+ *   pose             : 16 fp32, COLUMN-major 4x4                 == Eigen::Matrix4f::data()
+ *   intrinsics       : fx, fy, cx, cy of the depth camera        (Matrix3f K: K(0,0),K(1,1),K(0,2),K(1,2))
+ *   max_distance     : SQUARED metres                            (NearestNeighbor.h:16-18, ICPOptimizer.h:154)
+ * All functions return ICP_OK (0) or an error code; nothing ever spins (the reference's ASSERT
+ * hangs in while(1), Eigen.h:9).  Host pointers only; the context owns every device buffer.
+ * One host thread per context; contexts are independent (one per GPU / HIP stream).
+ * ===================================================================================== */
+#ifndef ICP_HIP_H
+#define ICP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct icp_ctx icp_ctx;
+
+/* struct Match, NearestNeighbor.h:7-10.  idx = -1 => no match. */
+typedef struct icp_match_t { int32_t idx; float weight; } icp_match_t;
+
+enum icp_status {
+    ICP_OK = 0,
+    ICP_ERR_INVALID_ARG = 1,
+    ICP_ERR_HIP = 2,                 /* a HIP runtime call failed; see icp_last_error() */
+    ICP_ERR_NO_TARGET = 3,           /* "index needs to be build before querying" NearestNeighbor.h:144-147,335-338 */
+    ICP_ERR_NO_SOURCE = 4,
+    ICP_ERR_NO_CAMERA = 5,           /* "Set camera params before querying"        NearestNeighbor.h:341-344 */
+    ICP_ERR_TARGET_SIZE = 6,         /* "Invalid size of target points"            NearestNeighbor.h:346-349 */
+    ICP_ERR_COLOR_MISMATCH = 7,      /* 3-D index queried with colours or vice versa NearestNeighbor.h:149-152,240-243 */
+    ICP_ERR_NO_CORRESPONDENCES = 8,  /* reference ASSERT (ICPOptimizer.h:668,680,788) -- reported, never a hang */
+    ICP_ERR_NO_DEVICE = 9
+};
+
+/* enum values mirror the reference */
+enum { ICP_METRIC_POINT_TO_POINT = 0, ICP_METRIC_POINT_TO_PLANE = 1, ICP_METRIC_SYMMETRIC = 2 };   /* ICPOptimizer.h:46-48,131-136 */
+enum { ICP_MATCH_KNN = 0, ICP_MATCH_PROJECTIVE = 1 };                                               /* ICPOptimizer.h:71-78 */
+enum { ICP_WEIGHT_CONSTANT = 0, ICP_WEIGHT_DISTANCES = 1, ICP_WEIGHT_NORMALS = 2, ICP_WEIGHT_COLORS = 3 };   /* weighting.h:8 */
+enum { ICP_KNN_BRUTE_FORCE = 0, ICP_KNN_GRID = 1 };   /* both exact, identical (d2, lowest-index) argmin */
+
+/* The setter surface of ICPOptimizer (ICPOptimizer.h:41-95) as one POD. */
+typedef struct icp_params {
+    int32_t metric;          /* setMetric                     default 0           */
+    int32_t matching;        /* setMatchingMethod             default 0 (k-NN)    */
+    int32_t weighting;       /* setWeightingMethod            default 0           */
+    int32_t rejection;       /* setRejectionMethod            default 1 (60 deg)  */
+    int32_t color_icp;       /* enableColorICP                default 0           */
+    int32_t multires;        /* enableMultiResolution         default 0           */
+    int32_t n_iterations;    /* setNbOfIterations             default 20          */
+    float   max_distance;    /* setMatchingMaxDistance        default 0.0003f, squared metres */
+    float   fx, fy, cx, cy;  /* setCameraParamsMatchingMethod (ICPOptimizer.h:80-82) */
+    int32_t width, height;
+    int32_t knn_backend;     /* ICP_KNN_* (extension; the reference uses an approximate FLANN kd-tree) */
+    int32_t record_rmse;     /* 1: per-iteration RMSE against the convergence reference (ConvergenceMeasure.h:50-66) */
+} icp_params;
+
+/* Per-iteration record (what the reference prints / records each iteration, ICPOptimizer.h:541-631). */
+typedef struct icp_iter_stats {
+    int32_t n_src;           /* source points matched this iteration (multires level size) */
+    int32_t n_valid;         /* correspondences that entered the solve (ICPOptimizer.h:594-610) */
+    float   pose[16];        /* estimatedPose after the iteration, column-major */
+    float   rmse;            /* RMSE vs convergence reference, or -1 */
+    int32_t status;          /* ICP_OK or ICP_ERR_NO_CORRESPONDENCES for this iteration */
+} icp_iter_stats;
+
+/* Stage times of the last icp_run, device milliseconds from HIP events: the TimeMeasure breakdown
+ * (TimeMeasure.h:20-26).  Weighting, rejection and system build are one fused kernel here. */
+typedef struct icp_timing {
+    double match_ms;         /* matchingTime                                   */
+    double weight_reject_build_ms;   /* weighingTime + rejectionTime + system build */
+    double solve_ms;         /* reduction + linear solve + pose composition    */
+    double total_ms;         /* convergenceTime                                 */
+    int32_t iterations;
+} icp_timing;
+
+/* -------- context -------- */
+int icp_ctx_create(int device, icp_ctx** out);
+/* Same, but all work is enqueued on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream). */
+int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out);
+int icp_ctx_destroy(icp_ctx* ctx);
+const char* icp_last_error(const icp_ctx* ctx);
+
+/* -------- configuration: ICPOptimizer setters, ICPOptimizer.h:41-95 -------- */
+int icp_params_default(icp_params* p);                       /* ICPOptimizer ctor defaults, ICPOptimizer.h:29-37 */
+int icp_set_params(icp_ctx* ctx, const icp_params* p);
+int icp_get_params(const icp_ctx* ctx, icp_params* p);
+
+/* -------- NearestNeighborSearch::buildIndex, NearestNeighbor.h:24,27 (122-141, 209-232, 324-331) --------
+ * Uploads the target once per pair (AoS -> SoA on the device).  normals may be NULL when only
+ * icp_query_matches is used; rgba may be NULL unless color_icp / colour weighting is on. */
+int icp_set_target(icp_ctx* ctx, const float* xyz, const float* normals, const uint8_t* rgba, int32_t n);
+/* Source cloud of estimatePose (ICPOptimizer.h:140); resident across iterations. */
+int icp_set_source(icp_ctx* ctx, const float* xyz, const float* normals, const uint8_t* rgba, int32_t n);
+
+/* -------- NearestNeighborSearch::queryMatches, NearestNeighbor.h:25,28 --------
+ * transformed_xyz are ALREADY transformed query points (exactly the argument the reference passes);
+ * rgba != NULL selects the 6-D colour search (the target must have been set with colours). */
+int icp_query_matches(icp_ctx* ctx, const float* transformed_xyz, const uint8_t* rgba, int32_t n, icp_match_t* out);
+
+/* -------- single stages on the resident source (parity-test entry points) --------
+ * icp_match      : transformPoints (utils.h:106-118) fused with queryMatches; d2_out (optional) = winning
+ *                  squared distance (FLT_MAX when no candidate).
+ * icp_correspond : + applyWeights (weighting.h:39-99) + pruneCorrespondences (ICPOptimizer.h:157-174) +
+ *                  validity filter (ICPOptimizer.h:594-610).  sums_out (optional, 64 doubles) receives the
+ *                  reduced accumulators the solver consumes (layout in DESIGN.md), n_valid_out the count. */
+int icp_match(icp_ctx* ctx, const float pose[16], icp_match_t* out, float* d2_out);
+int icp_correspond(icp_ctx* ctx, const float pose[16], icp_match_t* out, double* sums_out, int32_t* n_valid_out);
+
+/* -------- one iteration / the whole loop: LinearICPOptimizer::estimatePose, ICPOptimizer.h:493-663 --------
+ * pose_inout is the caller-owned in/out initialPose (ICPOptimizer.h:140,538,659).
+ * icp_iterate runs stages 2-5 once on the full-resolution source (no multires bookkeeping).
+ * icp_run runs n_iterations (or the multi-resolution schedule, ICPOptimizer.h:503-525,634-655) without
+ * any host round trip inside the loop; stats (optional) receives up to max_stats records. */
+int icp_iterate(icp_ctx* ctx, float pose_inout[16], icp_iter_stats* stats);
+int icp_run(icp_ctx* ctx, float pose_inout[16], icp_iter_stats* stats, int32_t max_stats, int32_t* n_iterations_run);
+int icp_get_timing(const icp_ctx* ctx, icp_timing* out);
+/* The iteration schedule icp_run will execute (pure host logic, no device needed): one decimation factor per
+ * iteration, 0 = full cloud without selection.  ICPOptimizer.h:503-516,540,634-655 / PointCloud.h:325-343. */
+int icp_schedule(const icp_params* p, int32_t n_src, int32_t* factors_out, int32_t max_out, int32_t* count_out);
+
+/* -------- ConvergenceMeasure (ConvergenceMeasure.h:30-66): known-correspondence RMSE --------
+ * src_xyz[i] (moved by the estimated pose) is compared with ref_xyz[i]. */
+int icp_set_convergence_reference(icp_ctx* ctx, const float* src_xyz, const float* ref_xyz, int32_t n);
+int icp_rmse(icp_ctx* ctx, const float pose[16], float* rmse_out);
+
+/* -------- utils.h:106-133 on the device (used by the adaptor for transformPoints/Normals) -------- */
+int icp_transform_points(icp_ctx* ctx, const float* xyz, int32_t n, const float pose[16], float* out);
+int icp_transform_normals(icp_ctx* ctx, const float* normals, int32_t n, const float pose[16], float* out);
+
+/* Library identification: returns e.g. "icp_hip gfx950 <build id>". */
+const char* icp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICP_HIP_H */

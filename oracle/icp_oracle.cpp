@@ -375,6 +375,62 @@ int solve_symmetric_t(const float* s, const float* d, const float* ns, const flo
     return 0;
 }
 
+
+// ---- exact kd-tree 1-NN (CPU stand-in for the FLANN index the optimizer instantiates) ----------
+// NearestNeighbor.h:122-141 builds flann::KDTreeIndexParams(1) and :172-174 queries it with 16 checks:
+// approximate and randomised, hence not reproducible.  This tree is EXACT: leaves evaluate the same fp32
+// distance as orc_knn3 and candidates are compared lexicographically (d2, index), so the result is
+// bit-identical to the brute-force scan; pruning uses a plane-distance bound with a 1e-5 relative safety
+// margin (fp32 rounding of d2 is < 4e-7 relative).  Used to check full-size GPU results and as the CPU baseline.
+struct KdNode { int left, right; int begin, end; int dim; float split; float lo[3], hi[3]; };
+struct KdTree {
+    std::vector<KdNode> nodes; std::vector<int> perm; std::vector<float> pts;   // pts: reordered copy, 3 per point
+    int m = 0;
+};
+static int kd_build(KdTree& t, const float* tgt, int begin, int end) {
+    KdNode nd; nd.begin = begin; nd.end = end; nd.left = nd.right = -1; nd.dim = 0; nd.split = 0;
+    for (int k = 0; k < 3; k++) { nd.lo[k] = std::numeric_limits<float>::infinity(); nd.hi[k] = -std::numeric_limits<float>::infinity(); }
+    for (int i = begin; i < end; i++) for (int k = 0; k < 3; k++) { float v = tgt[(size_t)t.perm[i]*3+k]; if (v < nd.lo[k]) nd.lo[k] = v; if (v > nd.hi[k]) nd.hi[k] = v; }
+    int id = (int)t.nodes.size(); t.nodes.push_back(nd);
+    if (end - begin > 16) {
+        int dim = 0; float ext = -1;
+        for (int k = 0; k < 3; k++) { float e = nd.hi[k] - nd.lo[k]; if (e > ext) { ext = e; dim = k; } }
+        if (ext > 0 && std::isfinite(ext)) {
+            int mid = (begin + end) / 2;
+            std::nth_element(t.perm.begin() + begin, t.perm.begin() + mid, t.perm.begin() + end,
+                             [&](int a, int b) { return tgt[(size_t)a*3+dim] < tgt[(size_t)b*3+dim]; });
+            t.nodes[id].dim = dim; t.nodes[id].split = tgt[(size_t)t.perm[mid]*3+dim];
+            int l = kd_build(t, tgt, begin, mid); int r = kd_build(t, tgt, mid, end);
+            t.nodes[id].left = l; t.nodes[id].right = r;
+        }
+    }
+    return id;
+}
+static inline double kd_box_d2(const KdNode& nd, const float* p) {   // squared distance to the node's bounding box (fp64, lower bound)
+    double s = 0;
+    for (int k = 0; k < 3; k++) { double d = 0; if (p[k] < nd.lo[k]) d = (double)nd.lo[k] - p[k]; else if (p[k] > nd.hi[k]) d = (double)p[k] - nd.hi[k]; s += d * d; }
+    return s;
+}
+static void kd_query(const KdTree& t, int id, const float* p, float& best, int& bi) {
+    const KdNode& nd = t.nodes[id];
+    if (nd.left < 0) {
+        for (int i = nd.begin; i < nd.end; i++) {
+            const float* q = &t.pts[(size_t)i*3];
+            float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+            float dist = (dx*dx + dy*dy) + dz*dz;
+            int j = t.perm[i];
+            if (dist < best || (dist == best && j < bi && bi >= 0)) { best = dist; bi = j; }
+        }
+        return;
+    }
+    const KdNode& L = t.nodes[nd.left]; const KdNode& R = t.nodes[nd.right];
+    double dl = kd_box_d2(L, p), dr = kd_box_d2(R, p);
+    int first = nd.left, second = nd.right; double d1 = dl, d2 = dr;
+    if (dr < dl) { first = nd.right; second = nd.left; d1 = dr; d2 = dl; }
+    if (!(d1 * (1.0 - 1e-5) > (double)best)) kd_query(t, first, p, best, bi);
+    if (!(d2 * (1.0 - 1e-5) > (double)best)) kd_query(t, second, p, best, bi);
+}
+
 }  // namespace
 
 // =====================================================================================
@@ -407,6 +463,32 @@ void orc_knn3(const float* q, int n, const float* tgt, int m, float max_dist, Or
             float dist = (dx*dx + dy*dy) + dz*dz;              // flann::L2<float> order
             if (best > dist) { bi = j; best = dist; }          // strict: first minimum
         }
+        if (best <= max_dist) { out[i].idx = bi; out[i].weight = 1.f; } else { out[i].idx = -1; out[i].weight = 0.f; }
+        if (d2_out) d2_out[i] = best;
+    }
+}
+
+
+// buildIndex + queryMatches through the exact kd-tree; results are bit-identical to orc_knn3.
+void* orc_kdtree_build(const float* tgt, int m) {
+    KdTree* t = new KdTree(); t->m = m; t->perm.resize(m);
+    // non-finite targets can never win the strict-< argmin (their distance is inf/NaN): leave them out of the tree
+    int cnt = 0; for (int i = 0; i < m; i++) if (finite3(tgt + (size_t)i*3)) t->perm[cnt++] = i;
+    t->perm.resize(cnt);
+    if (cnt > 0) kd_build(*t, tgt, 0, cnt);
+    t->pts.resize((size_t)cnt*3);
+    for (int i = 0; i < cnt; i++) std::memcpy(&t->pts[(size_t)i*3], tgt + (size_t)t->perm[i]*3, 12);
+    return t;
+}
+void orc_kdtree_free(void* h) { delete (KdTree*)h; }
+void orc_kdtree_query(const void* h, const float* q, int n, float max_dist, OrcMatch* out, float* d2_out) {
+    const KdTree& t = *(const KdTree*)h;
+    #pragma omp parallel for schedule(dynamic, 256)
+    for (int i = 0; i < n; i++) {
+        float best = std::numeric_limits<float>::max(); int bi = -1;
+        const float* p = q + (size_t)i*3;
+        if (!t.nodes.empty() && finite3(p)) kd_query(t, 0, p, best, bi);
+        if (bi < 0) best = std::numeric_limits<float>::max();
         if (best <= max_dist) { out[i].idx = bi; out[i].weight = 1.f; } else { out[i].idx = -1; out[i].weight = 0.f; }
         if (d2_out) d2_out[i] = best;
     }
@@ -583,6 +665,8 @@ struct OrcParams {
     float max_distance;  // squared metres                           :41-44
     float fx, fy, cx, cy; int width, height;                      // setCameraParams
     int window;          // 12                                       NearestNeighbor.h:319
+    int knn_kdtree;      // oracle knob: 1 = exact kd-tree matcher (same results as the brute-force scan, faster)
+    void* kdtree;        // cached tree handle (built by orc_estimate_pose / the caller)
 };
 
 struct OrcIterRecord { int n_src; int n_valid; float pose[16]; double seconds_match; double seconds_rest; };
@@ -601,6 +685,7 @@ int orc_iterate(const OrcParams* prm, const float* sp0, const float* sn0, const 
     double t0 = now_s();
     if (prm->matching == 1) orc_projective(sp.data(), n, tp, prm->width, prm->height, prm->fx, prm->fy, prm->cx, prm->cy, prm->max_distance, prm->window, mt.data(), nullptr);
     else if (prm->color_icp) orc_knn6(sp.data(), sc, n, tp, tc, m, prm->max_distance, mt.data(), nullptr);   // :562-563
+    else if (prm->knn_kdtree && prm->kdtree) orc_kdtree_query(prm->kdtree, sp.data(), n, prm->max_distance, mt.data(), nullptr);
     else orc_knn3(sp.data(), n, tp, m, prm->max_distance, mt.data(), nullptr);                                // :565
     double t1 = now_s();
     orc_apply_weights(prm->weighting, prm->max_distance, sp.data(), tp, sn.data(), tn, sc, tc, mt.data(), n);   // :571
@@ -627,6 +712,10 @@ int orc_iterate(const OrcParams* prm, const float* sp0, const float* sn0, const 
 int orc_estimate_pose(const OrcParams* prm, const float* sp, const float* sn, const unsigned char* sc, int n,
                       const float* tp, const float* tn, const unsigned char* tc, int m, float* pose,
                       OrcIterRecord* records, int max_records) {
+    OrcParams local = *prm; void* owned = nullptr;
+    if (local.knn_kdtree && !local.kdtree && local.matching == 0 && !local.color_icp) { owned = orc_kdtree_build(tp, m); local.kdtree = owned; }   // buildIndex :532-535
+    prm = &local;
+    struct Guard { void* h; ~Guard() { if (h) orc_kdtree_free(h); } } guard{owned};
     float currentResolution = 1.0f; int originalSize = n;
     if (prm->multires) {                                          // :505-516
         while (1) { originalSize = (int)(originalSize / 2.0); if (originalSize < 100) break; currentResolution *= 2.0f; }

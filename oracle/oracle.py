@@ -35,7 +35,7 @@ class Params(C.Structure):
     _fields_ = [("metric", C.c_int), ("matching", C.c_int), ("weighting", C.c_int), ("rejection", C.c_int),
                 ("color_icp", C.c_int), ("multires", C.c_int), ("n_iterations", C.c_int), ("solver_mode", C.c_int),
                 ("max_distance", C.c_float), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
-                ("width", C.c_int), ("height", C.c_int), ("window", C.c_int)]
+                ("width", C.c_int), ("height", C.c_int), ("window", C.c_int), ("knn_kdtree", C.c_int), ("kdtree", C.c_void_p)]
 
 
 class IterRecord(C.Structure):
@@ -44,7 +44,7 @@ class IterRecord(C.Structure):
 
 
 def make_params(metric=0, matching=0, weighting=0, rejection=1, color_icp=0, multires=0, n_iterations=20,
-                solver_mode=0, max_distance=0.0003, K=None, width=0, height=0, window=12):
+                solver_mode=0, max_distance=0.0003, K=None, width=0, height=0, window=12, knn_kdtree=0):
     p = Params()
     p.metric, p.matching, p.weighting, p.rejection = metric, matching, weighting, rejection
     p.color_icp, p.multires, p.n_iterations, p.solver_mode = int(color_icp), int(multires), n_iterations, solver_mode
@@ -53,6 +53,7 @@ def make_params(metric=0, matching=0, weighting=0, rejection=1, color_icp=0, mul
         K = np.asarray(K, dtype=np.float32)
         p.fx, p.fy, p.cx, p.cy = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
     p.width, p.height, p.window = width, height, window
+    p.knn_kdtree = int(knn_kdtree); p.kdtree = None
     return p
 
 
@@ -65,6 +66,7 @@ def lib():
         build()
         _lib = C.CDLL(_LIB)
         _lib.orc_rmse.restype = C.c_float
+        _lib.orc_kdtree_build.restype = C.c_void_p
     return _lib
 
 
@@ -112,6 +114,27 @@ def knn3(q, tgt, max_dist):
     out = np.empty(len(q), MATCH_DTYPE); d2 = np.empty(len(q), np.float32)
     lib().orc_knn3(_p(q), C.c_int(len(q)), _p(tgt), C.c_int(len(tgt)), C.c_float(max_dist), _p(out), _p(d2))
     return out, d2
+
+
+class KdTree:
+    """Exact kd-tree over a target cloud; query() is bit-identical to knn3() (see icp_oracle.cpp)."""
+
+    def __init__(self, tgt):
+        self.tgt = _f32(tgt)
+        self.h = C.c_void_p(lib().orc_kdtree_build(_p(self.tgt), C.c_int(len(self.tgt))))
+
+    def query(self, q, max_dist):
+        q = _f32(q)
+        out = np.empty(len(q), MATCH_DTYPE); d2 = np.empty(len(q), np.float32)
+        lib().orc_kdtree_query(self.h, _p(q), C.c_int(len(q)), C.c_float(max_dist), _p(out), _p(d2))
+        return out, d2
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_kdtree_free(self.h); self.h = None
+        except Exception:
+            pass
 
 
 def knn6(q, qrgba, tgt, trgba, max_dist):

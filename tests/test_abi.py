@@ -1,0 +1,76 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/icp_hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+import subprocess
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "icp_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"^\s*(?:int|const char\s*\*)\s+(icp_\w+)\s*\(", txt, flags=re.M)))
+
+
+def test_header_and_binding_agree():
+    from icp_amd import binding
+    assert header_functions() == sorted(binding.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    from icp_amd import binding
+    lib = binding.load_library()
+    for name in header_functions():
+        assert hasattr(lib, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", binding.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (icp_\w+)", out))
+    assert set(header_functions()) <= exported
+    assert lib.icp_version().decode().startswith("icp_hip gfx950")
+
+
+def test_library_contains_gfx950_code_object():
+    from icp_amd import binding
+    blob = open(binding.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"k_knn_brute" in blob
+
+
+def test_params_default_match_reference_ctor():
+    """ICPOptimizer ctor defaults, ICPOptimizer.h:29-31: metric 0, rejection 1, weighting 0, 20 iterations, 0.0003."""
+    from icp_amd import binding
+    p = binding.default_params()
+    assert (p.metric, p.matching, p.weighting, p.rejection, p.color_icp, p.multires, p.n_iterations) == (0, 0, 0, 1, 0, 0, 20)
+    assert np.float32(p.max_distance) == np.float32(0.0003)
+
+
+def test_struct_layouts():
+    from icp_amd import binding
+    assert ctypes.sizeof(binding.IcpParams) == 16 * 4
+    assert ctypes.sizeof(binding.IcpIterStats) == 4 + 4 + 64 + 4 + 4
+    assert binding.MATCH_DTYPE.itemsize == 8            # struct Match, NearestNeighbor.h:7-10
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a usable HIP device context creation fails loudly (ICP_ERR_NO_DEVICE) -- there is no CPU path."""
+    from icp_amd import binding
+    lib = binding.load_library()
+    h = ctypes.c_void_p()
+    rc = lib.icp_ctx_create(0, ctypes.byref(h))
+    if rc == 0:                                         # running on a GPU box: fine, just clean up
+        lib.icp_ctx_destroy(h)
+    else:
+        assert rc in (2, 9) and not h.value
+        with pytest.raises(binding.IcpError):
+            binding.Context(0)
+
+
+def test_product_never_imports_oracle():
+    """The shipped path (icp-variants_amd/, include/) must not reference the oracle."""
+    pkg = os.path.join(ROOT, "icp-variants_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "libicp_oracle" not in txt, f

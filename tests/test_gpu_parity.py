@@ -1,0 +1,344 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (libicp_hip.so), against the CPU oracle.
+
+Bar: bit-exact match indices / distances / weights (integer + fp32 with a fixed operation order); recovered pose
+within 1e-5 (rad / m) of the oracle's solve (north_star tolerance).  PARITY UNPINNED w.r.t. the reference binary
+(no reference golden vectors exist): the checker is the oracle, itself pinned in tests/test_oracle.py.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+POSE_TOL = 1e-5        # north_star: 1e-5 rad / 1e-5 m
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def rand_pose(seed, ang=0.1, tr=0.2):
+    from icp_amd import synth
+    r = np.random.default_rng(seed)
+    return synth.make_pose(r.uniform(-ang, ang, 3), r.uniform(-tr, tr, 3)).astype(f32)
+
+
+@pytest.fixture(scope="module")
+def small_pair():
+    from icp_amd import synth
+    return synth.eth_like_pair(0, n_tilt=43, n_beam=135)        # 5805 points
+
+
+@pytest.fixture(scope="module")
+def rgbd():
+    from icp_amd import synth
+    K = np.array([[131.25, 0, 79.5], [0, 131.25, 59.5], [0, 0, 1]], f32)      # TUM intrinsics / 4
+    return synth.rgbd_pair(0, width=160, height=120, K=K, hole_frac=0.05)
+
+
+def make_ctx(factory, tgt, src, **params):
+    c = factory()
+    for k, v in params.items():
+        setattr(c.params, k, v)
+    c.push_params()
+    c.set_target(*tgt)
+    if src is not None:
+        c.set_source(*src)
+    return c
+
+
+# ------------------------------------------------------------------------------------------- k-NN
+def test_knn3_bunny_identity_golden(gpu_ctx_factory, bunny, bunny_oracle):
+    c = make_ctx(gpu_ctx_factory, (bunny["tgt_pts"], bunny["tgt_nrm"], None), (bunny["src_pts"], bunny["src_nrm"], None), max_distance=0.0003)
+    m, d2 = c.match(np.eye(4))
+    assert np.array_equal(m["idx"], bunny_oracle["knn3_identity_idx"])
+    assert np.array_equal(bits(d2), bits(bunny_oracle["knn3_identity_d2"]))
+    assert int((m["idx"] >= 0).sum()) == 576
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_knn3_fused_transform_bit_exact(gpu_ctx_factory, orc, small_pair, seed):
+    """transformPoints fused into the matcher: same fp32 transformed coordinates => same argmin and d2 bits."""
+    p = small_pair
+    c = make_ctx(gpu_ctx_factory, (p["tgt_pts"], p["tgt_nrm"], None), (p["src_pts"], p["src_nrm"], None), max_distance=0.05)
+    T = rand_pose(seed)
+    m, d2 = c.match(T)
+    q = orc.transform_points(p["src_pts"], T)
+    mo, do = orc.knn3(q, p["tgt_pts"], 0.05)
+    assert np.array_equal(m["idx"], mo["idx"]) and np.array_equal(bits(d2), bits(do))
+    assert np.array_equal(bits(m["weight"]), bits(mo["weight"]))
+    assert np.array_equal(bits(c.transform_points(p["src_pts"], T)), bits(q))
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (1, 17), (63, 64), (65, 1000), (257, 15), (1000, 4097), (70001, 777)])
+def test_knn3_ragged_sizes_and_split_paths(gpu_ctx_factory, orc, n, m):
+    """Ragged tiles, single-point clouds, the target-split (atomicMin) path for few queries and the direct path
+    for many (70001 queries > 1024 blocks)."""
+    rng = np.random.default_rng(n * 131 + m)
+    q = rng.uniform(-2, 2, (n, 3)).astype(f32); t = rng.uniform(-2, 2, (m, 3)).astype(f32)
+    c = make_ctx(gpu_ctx_factory, (t, None, None), None, max_distance=0.5)
+    out = c.query_matches(q)
+    mo, do = orc.knn3(q, t, 0.5)
+    assert np.array_equal(out["idx"], mo["idx"]) and np.array_equal(bits(out["weight"]), bits(mo["weight"]))
+
+
+def test_knn3_ties_nan_inf_and_threshold(gpu_ctx_factory, orc):
+    rng = np.random.default_rng(7)
+    t = rng.uniform(-1, 1, (3000, 3)).astype(f32)
+    t[10] = np.nan; t[20] = -np.inf; t[21, 1] = np.inf; t[31] = t[30]; t[2500] = t[30]; t[2999] = t[0]
+    q = rng.uniform(-1, 1, (500, 3)).astype(f32)
+    q[0] = t[30]; q[1] = np.nan; q[2, 0] = np.inf; q[3] = t[0]; q[4] = -np.inf
+    # a query exactly half way between two targets: both distances equal -> lowest index
+    t[100] = [5, 5, 5]; t[50] = [5, 5, 6]; q[5] = [5, 5, 5.5]
+    for thr in (0.0, 1e-6, 0.01, 1e30):
+        c = make_ctx(gpu_ctx_factory, (t, None, None), (q, None, None), max_distance=thr)
+        m, d2 = c.match(np.eye(4))
+        mo, do = orc.knn3(q, t, thr)
+        assert np.array_equal(m["idx"], mo["idx"]) and np.array_equal(bits(d2), bits(do)), thr
+    assert mo["idx"][0] == 30 and mo["idx"][5] == 50 and mo["idx"][1] == -1
+
+
+def test_knn6_colour_bit_exact(gpu_ctx_factory, orc, rgbd):
+    """6-D (xyz + rgb/255) search, NearestNeighbor.h:209-303."""
+    from icp_amd import synth
+    sp, sn, sc = synth.compact_valid(rgbd["src_pts"], rgbd["src_nrm"], rgbd["src_rgba"])
+    tp, tn, tc = synth.compact_valid(rgbd["tgt_pts"], rgbd["tgt_nrm"], rgbd["tgt_rgba"])
+    sp, sn, sc = sp[::3], sn[::3], sc[::3]
+    c = make_ctx(gpu_ctx_factory, (tp, tn, tc), (sp, sn, sc), max_distance=0.1, color_icp=1)
+    T = rand_pose(5, 0.02, 0.02)
+    m, d2 = c.match(T)
+    q = orc.transform_points(sp, T)
+    mo, do = orc.knn6(q, sc, tp, tc, 0.1)
+    assert np.array_equal(m["idx"], mo["idx"]) and np.array_equal(bits(d2), bits(do))
+    # queryMatches(points, colours) overload
+    out = c.query_matches(q, sc)
+    assert np.array_equal(out["idx"], mo["idx"])
+    # colours change the answer w.r.t. the 3-D search (otherwise the test proves nothing)
+    m3, _ = orc.knn3(q, tp, 0.1)
+    assert (m3["idx"] != mo["idx"]).sum() > 10
+
+
+def test_query_matches_colour_mismatch_is_an_error(gpu_ctx_factory):
+    """NearestNeighbor.h:240-243: colour query against an index built without colours."""
+    from icp_amd import binding
+    t = np.zeros((10, 3), f32); q = np.zeros((4, 3), f32)
+    c = make_ctx(gpu_ctx_factory, (t, None, None), None)
+    with pytest.raises(binding.IcpError) as e:
+        c.query_matches(q, np.zeros((4, 4), np.uint8))
+    assert e.value.code == 7
+    c2 = gpu_ctx_factory()
+    with pytest.raises(binding.IcpError) as e:
+        c2.query_matches(q)                                            # :144-147 index not built
+    assert e.value.code == 3
+
+
+# ------------------------------------------------------------------------------------- projective
+def test_projective_bit_exact_with_quirks(gpu_ctx_factory, orc, rgbd):
+    """NearestNeighbor.h:333-421 incl. unsigned-underflow border, MINF holes, x == MINF -> Match{0,0.f}."""
+    W, H, K = rgbd["width"], rgbd["height"], rgbd["K"]
+    tp = rgbd["tgt_pts"]; sp = rgbd["src_pts"].copy(); sn = rgbd["src_nrm"]
+    sp[7] = [-np.inf, 0.1, 1.0]; sp[8] = [np.nan, 0.1, 1.0]; sp[9] = [0.1, 0.1, -1.0]; sp[10] = [0.1, 0.1, 0.0]; sp[11] = [1e30, 0.1, 1e-30]
+    c = make_ctx(gpu_ctx_factory, (tp, rgbd["tgt_nrm"], None), (sp, sn, None), matching=1, max_distance=0.1,
+                 fx=float(K[0, 0]), fy=float(K[1, 1]), cx=float(K[0, 2]), cy=float(K[1, 2]), width=W, height=H)
+    for T in (np.eye(4, dtype=f32), rgbd["gt"].astype(f32), rand_pose(3, 0.05, 0.05)):
+        m, d2 = c.match(T)
+        q = orc.transform_points(sp, T)
+        mo, do = orc.projective(q, tp, W, H, K, 0.1)
+        assert np.array_equal(m["idx"], mo["idx"]) and np.array_equal(bits(m["weight"]), bits(mo["weight"]))
+        assert np.array_equal(bits(d2), bits(do))
+    m, _ = c.match(np.eye(4))
+    assert (m["idx"][7], m["weight"][7]) == (0, 0.0)
+    assert (m["idx"] >= 0).sum() > 5000
+
+
+def test_projective_errors(gpu_ctx_factory, rgbd):
+    from icp_amd import binding
+    tp = rgbd["tgt_pts"]
+    c = make_ctx(gpu_ctx_factory, (tp, None, None), None, matching=1)
+    with pytest.raises(binding.IcpError) as e:
+        c.query_matches(tp[:10])
+    assert e.value.code == 5                                           # NearestNeighbor.h:341-344
+    c.params.width, c.params.height = 100, 100; c.push_params()
+    with pytest.raises(binding.IcpError) as e:
+        c.query_matches(tp[:10])
+    assert e.value.code == 6                                           # NearestNeighbor.h:346-349
+
+
+# ------------------------------------------------------------------------- weighting + rejection
+def oracle_post(orc, prm, sp, sn, sc, tp, tn, tc, T, matcher):
+    q = orc.transform_points(sp, T); qn = orc.transform_normals(sn, T)
+    m = matcher(q)
+    m = orc.apply_weights(prm["weighting"], prm["max_distance"], q, tp, qn, tn, sc, tc, m)
+    if prm["rejection"] == 1:
+        m = orc.prune(qn, tn, m)
+    return q, qn, m
+
+
+@pytest.mark.parametrize("weighting", [0, 1, 2, 3])
+@pytest.mark.parametrize("rejection", [0, 1])
+def test_weights_and_rejection_bit_exact(gpu_ctx_factory, orc, small_pair, weighting, rejection):
+    p = small_pair
+    sp, sn, sc, tp, tn, tc = p["src_pts"].copy(), p["src_nrm"].copy(), p["src_rgba"], p["tgt_pts"], p["tgt_nrm"].copy(), p["tgt_rgba"]
+    sn[5] = np.nan; tn[40] = np.inf; sp[9] = np.nan; sn[11] = 0                     # non-finite normals/points, zero normal
+    c = make_ctx(gpu_ctx_factory, (tp, tn, tc), (sp, sn, sc), max_distance=0.3, weighting=weighting, rejection=rejection, metric=1)
+    T = rand_pose(11, 0.03, 0.05)
+    m, sums, nv = c.correspond(T)
+    q, qn, mo = oracle_post(orc, dict(weighting=weighting, rejection=rejection, max_distance=0.3), sp, sn, sc, tp, tn, tc, T,
+                            lambda q: orc.knn3(q, tp, 0.3)[0])
+    assert np.array_equal(m["idx"], mo["idx"])
+    assert np.array_equal(bits(m["weight"]), bits(mo["weight"]))
+    cs, cd, cw, cnt, cns = orc.compact(q, qn, tp, tn, mo)
+    assert nv == len(cs)
+    if rejection:
+        assert (mo["idx"] < 0).sum() > (orc.knn3(q, tp, 0.3)[0]["idx"] < 0).sum()     # rejection really removed something
+    # accumulators of the fused kernel vs fp64 numpy on the oracle's compacted arrays
+    assert sums[0] == len(cs)
+    assert np.allclose(sums[1:4], cs.astype(np.float64).sum(0), rtol=1e-12) and np.allclose(sums[4:7], cd.astype(np.float64).sum(0), rtol=1e-12)
+
+
+def test_normal_equations_match_fp64_numpy(gpu_ctx_factory, orc, small_pair):
+    """J^T J / J^T r of the point-to-plane rows (ICPOptimizer.h:698-750): fp32 rows, fp64 products."""
+    p = small_pair
+    c = make_ctx(gpu_ctx_factory, (p["tgt_pts"], p["tgt_nrm"], None), (p["src_pts"], p["src_nrm"], None), max_distance=0.3, weighting=1, metric=1)
+    T = rand_pose(12, 0.03, 0.05)
+    m, sums, nv = c.correspond(T)
+    q = orc.transform_points(p["src_pts"], T); qn = orc.transform_normals(p["src_nrm"], T)
+    cs, cd, cw, cnt, cns = orc.compact(q, qn, p["tgt_pts"], p["tgt_nrm"], m)
+    s, d, n, w = cs, cd, cnt, cw
+    A0 = np.stack([n[:, 2] * s[:, 1] - n[:, 1] * s[:, 2], n[:, 0] * s[:, 2] - n[:, 2] * s[:, 0], n[:, 1] * s[:, 0] - n[:, 0] * s[:, 1], n[:, 0], n[:, 1], n[:, 2]], 1)
+    b0 = ((n[:, 0] * d[:, 0] + n[:, 1] * d[:, 1]) + n[:, 2] * d[:, 2]) - ((n[:, 0] * s[:, 0] + n[:, 1] * s[:, 1]) + n[:, 2] * s[:, 2])
+    f0 = f32(1.0) * w; f1 = f32(0.1) * w
+    z, o = np.zeros_like(w), np.ones_like(w)
+    rows = [A0 * f0[:, None], np.stack([z, s[:, 2], -s[:, 1], o, z, z], 1) * f1[:, None],
+            np.stack([-s[:, 2], z, s[:, 0], z, o, z], 1) * f1[:, None], np.stack([s[:, 1], -s[:, 0], z, z, z, o], 1) * f1[:, None]]
+    rhs = [b0 * f0, (d[:, 0] - s[:, 0]) * f1, (d[:, 1] - s[:, 1]) * f1, (d[:, 2] - s[:, 2]) * f1]
+    A = np.concatenate(rows).astype(np.float64); b = np.concatenate(rhs).astype(np.float64)
+    JtJ = A.T @ A; Jtr = A.T @ b
+    iu = np.triu_indices(6)
+    assert np.allclose(sums[7:28], JtJ[iu], rtol=1e-11, atol=1e-13)
+    assert np.allclose(sums[28:34], Jtr, rtol=1e-10, atol=1e-13)
+
+
+# ------------------------------------------------------------------------------- single iteration
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("weighting", [0, 1, 2])
+def test_single_iteration_pose(gpu_ctx_factory, orc, small_pair, metric, weighting):
+    """One full iteration from the same pose: identical matches, delta pose within 1e-5 of the oracle (both flavours)."""
+    p = small_pair
+    c = make_ctx(gpu_ctx_factory, (p["tgt_pts"], p["tgt_nrm"], p["tgt_rgba"]), (p["src_pts"], p["src_nrm"], p["src_rgba"]),
+                 max_distance=0.3, weighting=weighting, metric=metric)
+    T = rand_pose(20 + metric, 0.02, 0.03)
+    pose, st = c.iterate(T)
+    for mode in (1, 0):
+        prm = orc.make_params(metric=metric, weighting=weighting, n_iterations=1, max_distance=0.3, solver_mode=mode)
+        po, mo, nvo, _, _ = orc.iterate(prm, p["src_pts"], p["src_nrm"], p["src_rgba"], p["tgt_pts"], p["tgt_nrm"], p["tgt_rgba"], T)
+        assert st["n_valid"] == nvo
+        assert np.abs(pose - po).max() < POSE_TOL, (mode, np.abs(pose - po).max())
+    assert st["status"] == 0 and np.array_equal(st["pose"], pose)
+
+
+# --------------------------------------------------------------------------------------- full loop
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("weighting,multires", [(0, 0), (1, 0), (2, 0), (0, 1)])
+def test_bunny_full_run_vs_golden(gpu_ctx_factory, bunny, bunny_oracle, metric, weighting, multires):
+    """Data/bunny_experiments.csv linear rows (bunny003-005, 203-205, 303-305) + normals weighting: 20 iterations,
+    maxDist^2 = 0.0003.  Final pose within 1e-5 of both oracle flavours; per-iteration sizes identical."""
+    from conftest import pose_error
+    from icp_amd import binding
+    opt = binding.LinearICPOptimizer(0)
+    opt.setMatchingMethod(0); opt.setMatchingMaxDistance(0.0003)        # main.cpp:74-75
+    opt.setMetric(metric); opt.setNbOfIterations(20); opt.setWeightingMethod(weighting); opt.enableMultiResolution(bool(multires))
+    pose, recs = opt.estimatePose(dict(pts=bunny["src_pts"], nrm=bunny["src_nrm"], rgba=bunny["src_rgba"]),
+                                  dict(pts=bunny["tgt_pts"], nrm=bunny["tgt_nrm"], rgba=bunny["tgt_rgba"]), np.eye(4))
+    key = "m%d_w%d_r%d" % (metric, weighting, multires)
+    assert [r["n_src"] for r in recs] == bunny_oracle[key + "_mode1_nsrc"].tolist()
+    for mode in (1, 0):
+        gp = bunny_oracle[key + "_mode%d_poses" % mode]
+        ang, tr = pose_error(pose, gp[-1])
+        assert ang < POSE_TOL and tr < POSE_TOL, (mode, ang, tr)
+    assert [r["n_valid"] for r in recs][-1] == bunny_oracle[key + "_mode1_nvalid"][-1]
+    opt.ctx.close()
+
+
+def test_bunny_ground_truth_anchor_on_gpu(gpu_ctx_factory, bunny):
+    """main.cpp:110-120 anchor through the device RMSE (ConvergenceMeasure.h:50-66)."""
+    from icp_amd import binding
+    gs = bunny["src_pts"][bunny["gt_src_idx"]]; gt = bunny["tgt_pts"][bunny["gt_tgt_idx"]]
+    opt = binding.LinearICPOptimizer(0)
+    opt.setMatchingMaxDistance(0.0003); opt.setMetric(1); opt.setNbOfIterations(20)
+    opt.setConvergenceMeasure(gs, gt)
+    pose, recs = opt.estimatePose(dict(pts=bunny["src_pts"], nrm=bunny["src_nrm"]), dict(pts=bunny["tgt_pts"], nrm=bunny["tgt_nrm"]), np.eye(4))
+    assert opt.ctx.rmse(np.eye(4)) > 0.02
+    assert recs[-1]["rmse"] < 1e-3 and abs(recs[-1]["rmse"] - opt.ctx.rmse(pose)) < 1e-7
+    assert recs[0]["rmse"] > recs[-1]["rmse"]
+    opt.ctx.close()
+
+
+def test_rmse_matches_oracle(gpu_ctx_factory, orc, small_pair):
+    p = small_pair
+    c = gpu_ctx_factory()
+    src = p["src_pts"].copy(); ref = p["src_unperturbed"].copy(); src[3] = np.nan; ref[8] = np.inf
+    c.set_convergence_reference(src, ref)
+    T = p["gt"].astype(f32)
+    assert abs(c.rmse(T) - orc.rmse(src, ref, T)) < 1e-6
+    assert abs(c.rmse(np.eye(4)) - orc.rmse(src, ref, np.eye(4))) < 1e-6
+
+
+def test_projective_symmetric_run(gpu_ctx_factory, orc, rgbd):
+    """Config 3 shape: projective matching + rejection + symmetric linear, organised target with holes."""
+    from conftest import pose_error
+    W, H, K = rgbd["width"], rgbd["height"], rgbd["K"]
+    c = make_ctx(gpu_ctx_factory, (rgbd["tgt_pts"], rgbd["tgt_nrm"], None), (rgbd["src_pts"], rgbd["src_nrm"], None), matching=1, metric=2,
+                 max_distance=0.1, n_iterations=12, fx=float(K[0, 0]), fy=float(K[1, 1]), cx=float(K[0, 2]), cy=float(K[1, 2]), width=W, height=H)
+    pose, recs, rc = c.run(np.eye(4))
+    prm = orc.make_params(metric=2, matching=1, n_iterations=12, max_distance=0.1, K=K, width=W, height=H, solver_mode=1)
+    po, ro = orc.estimate_pose(prm, rgbd["src_pts"], rgbd["src_nrm"], None, rgbd["tgt_pts"], rgbd["tgt_nrm"], None, np.eye(4))
+    assert [r["n_valid"] for r in recs][0] == ro[0]["n_valid"]
+    ang, tr = pose_error(pose, po)
+    assert ang < POSE_TOL and tr < POSE_TOL
+    ang, tr = pose_error(pose, rgbd["gt"])
+    assert ang < 2e-3 and tr < 5e-3                                     # and it actually registers the frames
+
+
+def test_colour_icp_multires_run(gpu_ctx_factory, orc, rgbd):
+    """Config 5 shape: 6-D k-NN + colour weighting + multi-resolution (ICPOptimizer.h:503-525,634-655)."""
+    from conftest import pose_error
+    from icp_amd import synth
+    tp, tn, tc = synth.compact_valid(rgbd["tgt_pts"], rgbd["tgt_nrm"], rgbd["tgt_rgba"])
+    sp, sn, sc = rgbd["src_pts"], rgbd["src_nrm"], rgbd["src_rgba"]          # multires keeps invalid points (main.cpp:292-293)
+    c = make_ctx(gpu_ctx_factory, (tp, tn, tc), (sp, sn, sc), color_icp=1, weighting=3, multires=1, metric=1, max_distance=0.1, n_iterations=10)
+    pose, recs, rc = c.run(np.eye(4))
+    prm = orc.make_params(metric=1, color_icp=1, weighting=3, multires=1, n_iterations=10, max_distance=0.1, solver_mode=1)
+    po, ro = orc.estimate_pose(prm, sp, sn, sc, tp, tn, tc, np.eye(4))
+    assert [r["n_src"] for r in recs] == [r["n_src"] for r in ro]
+    assert [r["n_valid"] for r in recs][:3] == [r["n_valid"] for r in ro][:3]
+    ang, tr = pose_error(pose, po)
+    assert ang < POSE_TOL and tr < POSE_TOL
+
+
+def test_no_correspondences_is_reported_not_a_hang(gpu_ctx_factory, bunny):
+    """The reference ASSERT spins forever (Eigen.h:9, ICPOptimizer.h:680); the library returns a status code."""
+    from icp_amd import binding
+    far = bunny["src_pts"] + f32(100.0)
+    c = make_ctx(gpu_ctx_factory, (bunny["tgt_pts"], bunny["tgt_nrm"], None), (far, bunny["src_nrm"], None), max_distance=0.0003, metric=1, n_iterations=3)
+    pose, recs, rc = c.run(np.eye(4), check=False)
+    assert rc == binding.ERR_NO_CORRESPONDENCES
+    assert all(r["n_valid"] == 0 and r["status"] == binding.ERR_NO_CORRESPONDENCES for r in recs)
+    assert np.array_equal(pose, np.eye(4, dtype=f32))                   # pose untouched
+
+
+def test_context_reuse_across_pairs(gpu_ctx_factory, orc, bunny, small_pair):
+    """One optimizer object reused across pairs with buildIndex per call (main.cpp:351,411): no stale state."""
+    c = gpu_ctx_factory()
+    c.params.max_distance = 0.3; c.params.metric = 1; c.params.n_iterations = 3; c.push_params()
+    p = small_pair
+    c.set_target(p["tgt_pts"], p["tgt_nrm"]); c.set_source(p["src_pts"], p["src_nrm"])
+    a, _, _ = c.run(np.eye(4))
+    c.params.max_distance = 0.0003; c.push_params()
+    c.set_target(bunny["tgt_pts"], bunny["tgt_nrm"]); c.set_source(bunny["src_pts"], bunny["src_nrm"])
+    m, d2 = c.match(np.eye(4))
+    mo, do = orc.knn3(bunny["src_pts"], bunny["tgt_pts"], 0.0003)
+    assert np.array_equal(m["idx"], mo["idx"])
+    c.params.max_distance = 0.3; c.push_params()
+    c.set_target(p["tgt_pts"], p["tgt_nrm"]); c.set_source(p["src_pts"], p["src_nrm"])
+    b, _, _ = c.run(np.eye(4))
+    assert np.array_equal(a, b)                                          # deterministic, bit-identical rerun
