@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--iterations", type=int, default=50, help="ICP iterations per step (main.cpp:366)")
-    ap.add_argument("--knn", choices=["brute", "grid"], default=os.environ.get("ICP_BENCH_KNN", "brute"))
+    ap.add_argument("--knn", choices=["brute", "lbvh"], default=os.environ.get("ICP_BENCH_KNN", "lbvh"))
     ap.add_argument("--n-tilt", type=int, default=344)
     ap.add_argument("--n-beam", type=int, default=1077)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -86,7 +86,7 @@ def main():
     opt.setMatchingMethod(0); opt.setMatchingMaxDistance(10.0)          # main.cpp:360-361
     opt.setMetric(1); opt.setNbOfIterations(args.iterations)             # main.cpp:364-366
     opt.setWeightingMethod(0); opt.setRejectionMethod(1)
-    opt.setKnnBackend(1 if args.knn == "grid" else 0)
+    opt.setKnnBackend(1 if args.knn == "lbvh" else 0)
     ctx = opt.ctx
     ctx.push_params()
     ctx.set_target(pair["tgt_pts"], pair["tgt_nrm"], None)              # resident in HBM before the timed region

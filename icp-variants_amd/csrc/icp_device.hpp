@@ -12,6 +12,8 @@
 //                       (NearestNeighbor.h:81-97 semantics, squared L2 + squared threshold :181-185);
 //                       DIM=6 adds rgb/255 (NearestNeighbor.h:209-303)
 //   k_knn_finalize      merges target-split partial results (packed u64 atomicMin) into Match records
+//   k_bvh_* / k_knn_bvh exact LBVH index (build once per pair = buildIndex, NearestNeighbor.h:122-141) and its query:
+//                       bit-identical argmin to k_knn_brute at O(log M) per query
 //   k_projective        NearestNeighborSearchProjective::queryMatches (NearestNeighbor.h:333-421)
 //   k_post              transformNormals (utils.h:122-133) + applyWeights (weighting.h:39-99) +
 //                       pruneCorrespondences (ICPOptimizer.h:157-174) + validity filter (:594-610) +
@@ -196,6 +198,202 @@ __global__ void k_knn_finalize(const unsigned long long* __restrict__ best64, in
     if (best <= max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
     out[k] = m;
     if (d2_out) d2_out[k] = best;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact kd-ordered BVH 1-NN: the index the reference builds once per pair (NearestNeighbor.h:122-141, a FLANN
+// kd-tree) rebuilt on the device as a balanced kd-tree in implicit heap layout, queried with the SAME fp32
+// distance and the same lexicographic (d2, lowest index) argmin as k_knn_brute -- bit-identical results,
+// O(log M) nodes per query instead of M distance evaluations.
+//   build : level by level, every node's points are sorted along the widest axis of the node's bounding box
+//           (one rocPRIM radix sort per level over keys (node id << 32 | ordered coordinate bits)); the implicit
+//           node k covers a fixed, leaf-aligned slice of the array, so the count-balanced median split is simply
+//           "first half / second half".  Leaves hold BVH_LEAF points (x, y, z, original index) = one 128-B line;
+//           node records hold BOTH child boxes (64 B) and are filled bottom-up.
+//   query : one lane = one query, depth-first "near child first" traversal with a per-lane stack in LDS.  A node is
+//           skipped only if its box lower bound exceeds the running best; the bound uses the same operation
+//           sequence as the point distance, so by monotonicity of IEEE rounding fl(d2(point)) >= fl(lb) for every
+//           point in the box (a 1e-5 relative margin is kept on top).  Equal distances resolve to the lowest
+//           original index, exactly like the strict-< scan (NearestNeighbor.h:87).
+constexpr int BVH_LEAF = 8;
+constexpr int BVH_MAXD = 24;
+constexpr int BVH_THREADS = 128;
+
+struct BvhNode { float lo0[3], hi0[3], lo1[3], hi1[3]; float pad[4]; };   // boxes of children 2k+1 and 2k+2, 64 B
+
+struct BvhView {
+    const float4* pts;      // [n_leaves * BVH_LEAF] kd-ordered points, w = original index bits; pads are +inf
+    const BvhNode* nodes;   // [Lp - 1] internal nodes in heap order (node k: children 2k+1, 2k+2; leaves start at Lp-1)
+    int n_valid;            // finite target points in the tree
+    int Lp;                 // leaves rounded up to a power of two
+};
+
+__device__ __forceinline__ unsigned int ordered_bits(float f) {          // monotone float -> uint map
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(unsigned int u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+// compaction of the finite targets: perm[0..n_valid) = their indices in increasing order (host supplies it)
+// Per-level bounding boxes of the nodes (ordered-uint atomics; a wave that lies inside one node reduces first).
+__global__ void k_bvh_level_boxes(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                  const int* __restrict__ perm, int n_valid, int seg_shift, unsigned int* __restrict__ boxes /* [nodes][6] */) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = i < n_valid;
+    const int j = act ? perm[i] : 0;
+    unsigned int v[6];
+    if (act) { const unsigned int a = ordered_bits(x[j]), b = ordered_bits(y[j]), c = ordered_bits(z[j]); v[0] = a; v[1] = b; v[2] = c; v[3] = a; v[4] = b; v[5] = c; }
+    else { v[0] = v[1] = v[2] = 0xFFFFFFFFu; v[3] = v[4] = v[5] = 0u; }
+    const int node = i >> seg_shift;
+    if (seg_shift >= 6) {            // segment size >= 64 and wave-aligned: the whole wave is in one node
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { v[k] = min(v[k], (unsigned int)__shfl_down((int)v[k], off, 64)); v[3 + k] = max(v[3 + k], (unsigned int)__shfl_down((int)v[3 + k], off, 64)); }
+        }
+        if ((threadIdx.x & 63) == 0 && (i < n_valid)) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { atomicMin(boxes + (size_t)node * 6 + k, v[k]); atomicMax(boxes + (size_t)node * 6 + 3 + k, v[3 + k]); }
+        }
+    } else if (act) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { atomicMin(boxes + (size_t)node * 6 + k, v[k]); atomicMax(boxes + (size_t)node * 6 + 3 + k, v[3 + k]); }
+    }
+}
+__global__ void k_bvh_reset_boxes(unsigned int* boxes, int n_nodes) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_nodes * 6) boxes[t] = ((t % 6) < 3) ? 0xFFFFFFFFu : 0u;
+}
+// sort key of every point at this level: (node id, coordinate along the node's widest axis)
+__global__ void k_bvh_level_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                 const int* __restrict__ perm, int n_valid, int seg_shift, const unsigned int* __restrict__ boxes,
+                                 unsigned long long* __restrict__ keys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_valid) return;
+    const int node = i >> seg_shift;
+    const unsigned int* b = boxes + (size_t)node * 6;
+    const float ex = from_ordered_bits(b[3]) - from_ordered_bits(b[0]);
+    const float ey = from_ordered_bits(b[4]) - from_ordered_bits(b[1]);
+    const float ez = from_ordered_bits(b[5]) - from_ordered_bits(b[2]);
+    const int axis = (ex >= ey && ex >= ez) ? 0 : (ey >= ez ? 1 : 2);
+    const int j = perm[i];
+    const float c = axis == 0 ? x[j] : (axis == 1 ? y[j] : z[j]);
+    keys[i] = ((unsigned long long)(unsigned int)node << 32) | ordered_bits(c);
+}
+__global__ void k_iota(int* p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = i; }
+
+__global__ void k_bvh_gather(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                             const int* __restrict__ sorted_idx, int n_valid, int n_slots, float4* __restrict__ pts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    float4 v;
+    if (i < n_valid) { const int j = sorted_idx[i]; v.x = x[j]; v.y = y[j]; v.z = z[j]; v.w = __int_as_float(j); }
+    else { v.x = INFINITY; v.y = INFINITY; v.z = INFINITY; v.w = __int_as_float(-1); }
+    pts[i] = v;
+}
+
+// Boxes of the children of the internal nodes [first, first + count), bottom-up.  child_is_leaf: children are leaves.
+__device__ __forceinline__ void child_box(const float4* __restrict__ pts, const BvhNode* __restrict__ nodes, int child, int Lp, int n_leaves,
+                                          bool child_is_leaf, float* lo, float* hi) {
+    lo[0] = lo[1] = lo[2] = INFINITY; hi[0] = hi[1] = hi[2] = -INFINITY;          // empty box: lower bound = +inf
+    if (child_is_leaf) {
+        const int leaf = child - (Lp - 1);
+        if (leaf < n_leaves) {
+            for (int k = 0; k < BVH_LEAF; k++) {
+                const float4 p = pts[(size_t)leaf * BVH_LEAF + k];
+                if (p.x < INFINITY) { lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z); hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z); }
+            }
+        }
+    } else {
+        const BvhNode nd = nodes[child];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lo[k] = fminf(nd.lo0[k], nd.lo1[k]); hi[k] = fmaxf(nd.hi0[k], nd.hi1[k]); }
+    }
+}
+__global__ void k_bvh_nodes(const float4* __restrict__ pts, int n_leaves, int Lp, int first, int count, int children_are_leaves, BvhNode* __restrict__ nodes) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int node = first + t;
+    BvhNode out;
+    child_box(pts, nodes, 2 * node + 1, Lp, n_leaves, children_are_leaves != 0, out.lo0, out.hi0);
+    child_box(pts, nodes, 2 * node + 2, Lp, n_leaves, children_are_leaves != 0, out.lo1, out.hi1);
+    out.pad[0] = out.pad[1] = out.pad[2] = out.pad[3] = 0.f;
+    nodes[node] = out;
+}
+
+// lower bound of the fp32 squared distance from p to any point of the box, same op order as the point distance
+__device__ __forceinline__ float box_lb(const float* lo, const float* hi, float px, float py, float pz) {
+    const float ex = fmaxf(fmaxf(lo[0] - px, px - hi[0]), 0.f);
+    const float ey = fmaxf(fmaxf(lo[1] - py, py - hi[1]), 0.f);
+    const float ez = fmaxf(fmaxf(lo[2] - pz, pz - hi[2]), 0.f);
+    return (ex * ex + ey * ey) + ez * ez;
+}
+
+__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, const BvhView bv) {
+    __shared__ int st_node[BVH_MAXD][BVH_THREADS];
+    __shared__ float st_lb[BVH_MAXD][BVH_THREADS];
+    const int tid = threadIdx.x;
+    const int k = blockIdx.x * BVH_THREADS + tid;
+    if (k >= kp.n) return;
+    const int i = kp.sel ? kp.sel[k] : k;
+    float px = kp.sx[i], py = kp.sy[i], pz = kp.sz[i];
+    if (!kp.pretransformed) { float a, b, c; xform_point(kp.ps->pose, px, py, pz, a, b, c); px = a; py = b; pz = c; }
+    float best = FLT_MAX; int bi = -1;
+#ifdef ICP_BVH_STATS
+    int n_nodes_v = 0, n_leaves_v = 0;
+#endif
+    if (finite3(px, py, pz) && bv.n_valid > 0) {
+        const int first_leaf = bv.Lp - 1;
+        int sp = 0, node = 0;
+        while (true) {
+            if (node >= first_leaf) {
+#ifdef ICP_BVH_STATS
+                n_leaves_v++;
+#endif
+                const float4* __restrict__ lp = bv.pts + (size_t)(node - first_leaf) * BVH_LEAF;
+#pragma unroll
+                for (int t = 0; t < BVH_LEAF; t++) {
+                    const float4 q = lp[t];
+                    const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
+                    const float d = (dx * dx + dy * dy) + dz * dz;
+                    const int j = __float_as_int(q.w);
+                    if (d < best || (d == best && j < bi)) { best = d; bi = j; }      // first minimum = lowest original index
+                }
+            } else {
+#ifdef ICP_BVH_STATS
+                n_nodes_v++;
+#endif
+                const BvhNode nd = bv.nodes[node];
+                const int c0 = 2 * node + 1;
+                const float l0 = box_lb(nd.lo0, nd.hi0, px, py, pz);
+                const float l1 = box_lb(nd.lo1, nd.hi1, px, py, pz);
+                const bool swap = l1 < l0;
+                const int nearc = swap ? c0 + 1 : c0, farc = swap ? c0 : c0 + 1;
+                const float ln = swap ? l1 : l0, lf = swap ? l0 : l1;
+                if (!(ln * 0.99999f > best)) {
+                    if (!(lf * 0.99999f > best)) { st_node[sp][tid] = farc; st_lb[sp][tid] = lf; sp++; }
+                    node = nearc;
+                    continue;
+                }
+            }
+            bool found = false;
+            while (sp > 0) {
+                --sp;
+                if (!(st_lb[sp][tid] * 0.99999f > best)) { node = st_node[sp][tid]; found = true; break; }
+            }
+            if (!found) break;
+        }
+    }
+    icp_match_t m;
+    if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
+    kp.out[k] = m;
+#ifdef ICP_BVH_STATS
+    if (kp.d2_out) kp.d2_out[k] = (float)(n_nodes_v + 4096 * n_leaves_v);
+#else
+    if (kp.d2_out) kp.d2_out[k] = best;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -436,34 +634,109 @@ __global__ __launch_bounds__(POST_THREADS) void k_sym_accumulate(const PostParam
 
 // ------------------------------------------------------------------------------------------------
 // fp64 small dense solvers, run by one thread of k_reduce_solve.
-__device__ inline void jacobi_eig_sym(double* A /* n x n, destroyed */, int n, double* V, double* ev) {
-    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+template <int n>
+__device__ inline void jacobi_eig_sym(double* A /* n x n, destroyed */, double* V, double* ev) {
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+#pragma unroll
+        for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    }
     for (int sweep = 0; sweep < 50; sweep++) {
         double off = 0.0, dg = 0.0;
-        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) { if (i != j) off += A[i * n + j] * A[i * n + j]; else dg += A[i * n + j] * A[i * n + j]; }
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+#pragma unroll
+            for (int j = 0; j < n; j++) { if (i != j) off += A[i * n + j] * A[i * n + j]; else dg += A[i * n + j] * A[i * n + j]; }
+        }
         if (off <= 1e-300 || off <= 1e-34 * dg) break;
-        for (int p = 0; p < n - 1; p++) for (int q = p + 1; q < n; q++) {
-            const double apq = A[p * n + q];
-            if (apq == 0.0) continue;
-            const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-            for (int k = 0; k < n; k++) { const double akp = A[k * n + p], akq = A[k * n + q]; A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq; }
-            for (int k = 0; k < n; k++) { const double apk = A[p * n + k], aqk = A[q * n + k]; A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk; }
-            for (int k = 0; k < n; k++) { const double vkp = V[k * n + p], vkq = V[k * n + q]; V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq; }
+#pragma unroll
+        for (int p = 0; p < n - 1; p++) {
+#pragma unroll
+            for (int q = p + 1; q < n; q++) {
+                const double apq = A[p * n + q];
+                if (apq != 0.0) {
+                    const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                    for (int k = 0; k < n; k++) { const double akp = A[k * n + p], akq = A[k * n + q]; A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq; }
+#pragma unroll
+                    for (int k = 0; k < n; k++) { const double apk = A[p * n + k], aqk = A[q * n + k]; A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk; }
+#pragma unroll
+                    for (int k = 0; k < n; k++) { const double vkp = V[k * n + p], vkq = V[k * n + q]; V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq; }
+                }
+            }
         }
     }
+#pragma unroll
     for (int i = 0; i < n; i++) ev[i] = A[i * n + i];
 }
 
-// Minimum-norm least-squares solution from the normal equations with JacobiSVD::solve's rank rule
-// (singular values <= 6*eps_f32*sigma_max dropped, ICPOptimizer.h:757-758).
+// Fast path: when the 6x6 normal matrix is comfortably full rank (every LDL^T pivot > 1e-9 x its diagonal entry,
+// i.e. far above the (6 eps_f32)^2 = 5e-13 relative eigenvalue cut of the SVD rule) the truncated-SVD solution IS the
+// plain solution and an unrolled fp64 LDL^T gives it in ~100 flops.  Otherwise: Jacobi eigen-decomposition.
+__device__ __forceinline__ bool solve_ldlt6(const double* sums, double* x) {
+    double a00 = sums[0], a01 = sums[1], a02 = sums[2], a03 = sums[3], a04 = sums[4], a05 = sums[5];
+    double a11 = sums[6], a12 = sums[7], a13 = sums[8], a14 = sums[9], a15 = sums[10];
+    double a22 = sums[11], a23 = sums[12], a24 = sums[13], a25 = sums[14];
+    double a33 = sums[15], a34 = sums[16], a35 = sums[17];
+    double a44 = sums[18], a45 = sums[19];
+    double a55 = sums[20];
+    const double g0 = sums[21], g1 = sums[22], g2 = sums[23], g3 = sums[24], g4 = sums[25], g5 = sums[26];
+    const double tol = 1e-9;
+    const double o00 = a00, o11 = a11, o22 = a22, o33 = a33, o44 = a44, o55 = a55;
+    // column 0
+    const double d0 = a00; if (!(d0 > tol * o00) || !(o00 > 0)) return false;
+    const double l10 = a01 / d0, l20 = a02 / d0, l30 = a03 / d0, l40 = a04 / d0, l50 = a05 / d0;
+    a11 -= l10 * a01; a12 -= l10 * a02; a13 -= l10 * a03; a14 -= l10 * a04; a15 -= l10 * a05;
+    a22 -= l20 * a02; a23 -= l20 * a03; a24 -= l20 * a04; a25 -= l20 * a05;
+    a33 -= l30 * a03; a34 -= l30 * a04; a35 -= l30 * a05;
+    a44 -= l40 * a04; a45 -= l40 * a05;
+    a55 -= l50 * a05;
+    const double d1 = a11; if (!(d1 > tol * o11)) return false;
+    const double l21 = a12 / d1, l31 = a13 / d1, l41 = a14 / d1, l51 = a15 / d1;
+    a22 -= l21 * a12; a23 -= l21 * a13; a24 -= l21 * a14; a25 -= l21 * a15;
+    a33 -= l31 * a13; a34 -= l31 * a14; a35 -= l31 * a15;
+    a44 -= l41 * a14; a45 -= l41 * a15;
+    a55 -= l51 * a15;
+    const double d2 = a22; if (!(d2 > tol * o22)) return false;
+    const double l32 = a23 / d2, l42 = a24 / d2, l52 = a25 / d2;
+    a33 -= l32 * a23; a34 -= l32 * a24; a35 -= l32 * a25;
+    a44 -= l42 * a24; a45 -= l42 * a25;
+    a55 -= l52 * a25;
+    const double d3 = a33; if (!(d3 > tol * o33)) return false;
+    const double l43 = a34 / d3, l53 = a35 / d3;
+    a44 -= l43 * a34; a45 -= l43 * a35;
+    a55 -= l53 * a35;
+    const double d4 = a44; if (!(d4 > tol * o44)) return false;
+    const double l54 = a45 / d4;
+    a55 -= l54 * a45;
+    const double d5 = a55; if (!(d5 > tol * o55)) return false;
+    // L z = g
+    const double z0 = g0;
+    const double z1 = g1 - l10 * z0;
+    const double z2 = g2 - l20 * z0 - l21 * z1;
+    const double z3 = g3 - l30 * z0 - l31 * z1 - l32 * z2;
+    const double z4 = g4 - l40 * z0 - l41 * z1 - l42 * z2 - l43 * z3;
+    const double z5 = g5 - l50 * z0 - l51 * z1 - l52 * z2 - l53 * z3 - l54 * z4;
+    // D y = z ; L^T x = y
+    const double x5 = z5 / d5;
+    const double x4 = z4 / d4 - l54 * x5;
+    const double x3 = z3 / d3 - l43 * x4 - l53 * x5;
+    const double x2 = z2 / d2 - l32 * x3 - l42 * x4 - l52 * x5;
+    const double x1 = z1 / d1 - l21 * x2 - l31 * x3 - l41 * x4 - l51 * x5;
+    const double x0 = z0 / d0 - l10 * x1 - l20 * x2 - l30 * x3 - l40 * x4 - l50 * x5;
+    x[0] = x0; x[1] = x1; x[2] = x2; x[3] = x3; x[4] = x4; x[5] = x5;
+    return true;
+}
+
 __device__ inline void solve_normal_svd(const double* sums /* 21 + 6 */, double* x) {
+    if (solve_ldlt6(sums, x)) return;
     double A[36], V[36], ev[6];
     int q = 0;
     for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { A[a * 6 + c] = sums[q]; A[c * 6 + a] = sums[q]; q++; }
     const double* g = sums + 21;
-    jacobi_eig_sym(A, 6, V, ev);
+    jacobi_eig_sym<6>(A, V, ev);
     double emax = 0.0;
     for (int i = 0; i < 6; i++) emax = fmax(emax, ev[i]);
     const double thr = 6.0 * 1.1920928955078125e-07;
@@ -512,7 +785,7 @@ __device__ inline void solve_fullpiv_lu6(double* M, double* rhs, double* x) {
 __device__ inline void procrustes_rotation(const double* A /* 3x3 row-major */, double* R) {
     double B[9], V[9], ev[3];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += A[k * 3 + i] * A[k * 3 + j]; B[i * 3 + j] = s; }
-    jacobi_eig_sym(B, 3, V, ev);
+    jacobi_eig_sym<3>(B, V, ev);
     int o[3] = {0, 1, 2};
     for (int a = 0; a < 2; a++) for (int b = a + 1; b < 3; b++) if (ev[o[b]] > ev[o[a]]) { const int t = o[a]; o[a] = o[b]; o[b] = t; }
     double Vs[9], U[9];
@@ -590,12 +863,13 @@ struct SolveParams {
     const double* rmse_partials; int rmse_blocks;   // unused here
 };
 
-__global__ __launch_bounds__(256) void k_reduce_solve(const SolveParams sp) {
+constexpr int SOLVE_THREADS = 1024;
+__global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParams sp) {
     __shared__ double tot[NSUM];
     // fixed-order reduction of the block partials: wave w owns sums w, w+4, ...; lanes stride the
     // blocks sequentially, then a shuffle tree -- identical order on every run.
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int a = w; a < NSUM; a += 4) {
+    for (int a = w; a < NSUM; a += SOLVE_THREADS / WAVE) {
         double x = 0.0;
         for (int b = lane; b < sp.nblocks; b += WAVE) x += sp.partials[(size_t)b * NSUM + a];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);

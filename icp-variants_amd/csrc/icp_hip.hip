@@ -4,8 +4,11 @@
 // There is NO CPU fallback: every entry point needs a HIP device and fails with ICP_ERR_HIP /
 // ICP_ERR_NO_DEVICE when none is usable.
 // =====================================================================================
-#include "icp_device.hpp"
+#include <cstring>
+#include <cstdio>
 #include <cmath>
+#include "icp_device.hpp"
+#include <rocprim/device/device_radix_sort.hpp>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -40,6 +43,15 @@ struct Cloud {
 
 struct Level { DevBuf idx; int n = 0; };
 
+// LBVH over the target (buildIndex): device buffers + the host-side facts needed to launch the build.
+struct Bvh {
+    bool valid = false;
+    int n_valid = 0, n_leaves = 0, Lp = 1;
+    DevBuf keys, keys2, vals, vals2, temp, pts, nodes, lvl;
+    std::vector<int> finite_idx;                     // indices of the finite target points, increasing
+    double build_ms = 0.0;
+};
+
 }  // namespace
 
 struct icp_ctx {
@@ -48,6 +60,7 @@ struct icp_ctx {
     bool owns_stream = false;
     icp_params prm;
     Cloud tgt, src, qry;                 // qry: scratch cloud of icp_query_matches
+    Bvh bvh;                             // exact LBVH index of the target (knn_backend == ICP_KNN_LBVH)
     std::vector<uint8_t> src_valid;      // host mask: finite point && finite normal (PointCloud.h:334)
     std::map<int, Level> levels;         // multires selections by decimation factor
     DevBuf ps, matches, d2, best64, partials, sums, stats, staging, rmse_partials, rmse_out;
@@ -151,6 +164,62 @@ int ensure_match_buffers(icp_ctx* c, int n) {
     return ICP_OK;
 }
 
+// Build the kd-ordered BVH of the resident target on the device (once per icp_set_target; = buildIndex).
+int build_bvh(icp_ctx* c) {
+    Bvh& b = c->bvh;
+    int rc;
+    hipEvent_t e0, e1;
+    HIPCK(c, hipEventCreate(&e0)); HIPCK(c, hipEventCreate(&e1));
+    HIPCK(c, hipEventRecord(e0, c->stream));
+    const int nv = b.n_valid;
+    b.n_leaves = (nv + BVH_LEAF - 1) / BVH_LEAF;
+    b.Lp = 1; while (b.Lp < b.n_leaves) b.Lp <<= 1;
+    int depth = 0; while ((1 << depth) < b.Lp) depth++;          // internal levels 0 .. depth-1
+    const int n_inner = b.Lp - 1;
+    const int n_slots = (b.n_leaves > 0 ? b.n_leaves : 1) * BVH_LEAF;
+    const int cap = nv > 0 ? nv : 1;
+    if ((rc = ensure(c, b.keys, (size_t)cap * 8))) return rc;
+    if ((rc = ensure(c, b.keys2, (size_t)cap * 8))) return rc;
+    if ((rc = ensure(c, b.vals, (size_t)cap * 4))) return rc;
+    if ((rc = ensure(c, b.vals2, (size_t)cap * 4))) return rc;
+    if ((rc = ensure(c, b.pts, (size_t)n_slots * 16))) return rc;
+    if ((rc = ensure(c, b.nodes, (size_t)(n_inner > 0 ? n_inner : 1) * sizeof(BvhNode)))) return rc;
+    if ((rc = ensure(c, b.lvl, (size_t)(b.Lp > 1 ? b.Lp / 2 : 1) * 6 * 4))) return rc;
+    const float* tx = c->tgt.x.as<float>(); const float* ty = c->tgt.y.as<float>(); const float* tz = c->tgt.z.as<float>();
+    int* perm = b.vals.as<int>(); int* perm2 = b.vals2.as<int>();
+    if (nv > 0) {
+        // finite targets in index order (host list from icp_set_target)
+        HIPCK(c, hipMemcpyAsync(perm, b.finite_idx.data(), (size_t)nv * 4, hipMemcpyHostToDevice, c->stream));
+        size_t temp_bytes = 0;
+        HIPCK(c, rocprim::radix_sort_pairs(nullptr, temp_bytes, b.keys.as<unsigned long long>(), b.keys2.as<unsigned long long>(), perm, perm2, (size_t)nv, 0, 64, c->stream));
+        if ((rc = ensure(c, b.temp, temp_bytes))) return rc;
+        const int gb = (nv + 255) / 256;
+        for (int d = 0; d < depth; d++) {
+            // segment (node) size at level d in points: BVH_LEAF * Lp / 2^d  = 1 << seg_shift
+            int seg_shift = 0; { long long seg = (long long)BVH_LEAF * b.Lp >> d; while ((1LL << seg_shift) < seg) seg_shift++; }
+            const int n_nodes = 1 << d;
+            hipLaunchKernelGGL(k_bvh_reset_boxes, dim3((n_nodes * 6 + 255) / 256), dim3(256), 0, c->stream, b.lvl.as<unsigned int>(), n_nodes);
+            hipLaunchKernelGGL(k_bvh_level_boxes, dim3(gb), dim3(256), 0, c->stream, tx, ty, tz, perm, nv, seg_shift, b.lvl.as<unsigned int>());
+            hipLaunchKernelGGL(k_bvh_level_keys, dim3(gb), dim3(256), 0, c->stream, tx, ty, tz, perm, nv, seg_shift, b.lvl.as<unsigned int>(), b.keys.as<unsigned long long>());
+            HIPCK(c, rocprim::radix_sort_pairs(b.temp.p, temp_bytes, b.keys.as<unsigned long long>(), b.keys2.as<unsigned long long>(), perm, perm2, (size_t)nv, 0, 32 + d, c->stream));
+            int* t = perm; perm = perm2; perm2 = t;
+        }
+    }
+    hipLaunchKernelGGL(k_bvh_gather, dim3((n_slots + 255) / 256), dim3(256), 0, c->stream, tx, ty, tz, perm, nv, n_slots, b.pts.as<float4>());
+    for (int d = depth - 1; d >= 0; d--) {
+        const int count = 1 << d, first = count - 1;
+        hipLaunchKernelGGL(k_bvh_nodes, dim3((count + 255) / 256), dim3(256), 0, c->stream, b.pts.as<float4>(), b.n_leaves, b.Lp, first, count,
+                           d == depth - 1 ? 1 : 0, b.nodes.as<BvhNode>());
+    }
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipEventRecord(e1, c->stream));
+    HIPCK(c, hipEventSynchronize(e1));
+    float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, e0, e1)); b.build_ms = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    b.valid = true;
+    return ICP_OK;
+}
+
 // Enqueue the matching stage (no sync).
 int launch_match(icp_ctx* c, const QuerySet& q) {
     const icp_params& p = c->prm;
@@ -175,6 +244,15 @@ int launch_match(icp_ctx* c, const QuerySet& q) {
     kp.tcr = c->tgt.cr.as<float>(); kp.tcg = c->tgt.cg.as<float>(); kp.tcb = c->tgt.cb.as<float>();
     kp.mpad = c->tgt.npad; kp.ps = c->ps.as<PoseState>(); kp.pretransformed = q.pretransformed; kp.max_dist = p.max_distance;
     kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr;
+    if (p.knn_backend == ICP_KNN_LBVH && !q.use_colors) {
+        if (!c->bvh.valid && (rc = build_bvh(c))) return rc;
+        BvhView bv; bv.pts = c->bvh.pts.as<float4>(); bv.nodes = c->bvh.nodes.as<BvhNode>();
+        bv.n_valid = c->bvh.n_valid; bv.Lp = c->bvh.Lp;
+        kp.nseg = 1;
+        hipLaunchKernelGGL(k_knn_bvh, dim3((q.n + BVH_THREADS - 1) / BVH_THREADS), dim3(BVH_THREADS), 0, c->stream, kp, bv);
+        HIPCK(c, hipGetLastError());
+        return ICP_OK;
+    }
     const int bx = (q.n + WAVE - 1) / WAVE;
     const int nch = kp.mpad / KNN_CH;
     int nseg = 1;
@@ -217,15 +295,15 @@ int launch_post_and_solve(icp_ctx* c, const int* sel, int n, icp_iter_stats* d_s
     sp.n_src = n; sp.update_pose = update_pose;
     if (p.metric == ICP_METRIC_SYMMETRIC) {
         sp.phase = 0; sp.stats = nullptr; sp.sums_out = nullptr;
-        hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(256), 0, c->stream, sp);       // means
+        hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(SOLVE_THREADS), 0, c->stream, sp);       // means
         hipLaunchKernelGGL(k_sym_accumulate, dim3(nb), dim3(POST_THREADS), 0, c->stream, pp);
         if (ev_after_post) HIPCK(c, hipEventRecord(ev_after_post, c->stream));
         sp.phase = 1; sp.stats = d_stats; sp.sums_out = d_sums_out;
-        hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(256), 0, c->stream, sp);
+        hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(SOLVE_THREADS), 0, c->stream, sp);
     } else {
         if (ev_after_post) HIPCK(c, hipEventRecord(ev_after_post, c->stream));
         sp.phase = 0; sp.stats = d_stats; sp.sums_out = d_sums_out;
-        hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(256), 0, c->stream, sp);
+        hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(SOLVE_THREADS), 0, c->stream, sp);
     }
     HIPCK(c, hipGetLastError());
     return ICP_OK;
@@ -315,6 +393,7 @@ int icp_ctx_destroy(icp_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release(c->tgt); release(c->src); release(c->qry); release(c->conv_src); release(c->conv_ref);
+    release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.pts); release(c->bvh.nodes); release(c->bvh.lvl);
     for (auto& kv : c->levels) release(kv.second.idx);
     release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->partials); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out);
@@ -340,7 +419,17 @@ int icp_set_target(icp_ctx* c, const float* xyz, const float* normals, const uin
     if (!c || !xyz || n <= 0) { if (c) c->err = "icp_set_target: null points or n <= 0"; return ICP_ERR_INVALID_ARG; }
     int rc;
     if ((rc = set_device(c))) return rc;
-    return upload_cloud(c, c->tgt, xyz, normals, rgba, n, true);
+    if ((rc = upload_cloud(c, c->tgt, xyz, normals, rgba, n, true))) return rc;
+    Bvh& b = c->bvh;
+    b.valid = false; b.n_valid = 0;
+    b.finite_idx.clear(); b.finite_idx.reserve((size_t)n);
+    for (int i = 0; i < n; i++) {         // non-finite targets can never win the strict-< argmin: they stay out of the tree
+        const float* q = xyz + (size_t)i * 3;
+        if (std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2])) b.finite_idx.push_back(i);
+    }
+    b.n_valid = (int)b.finite_idx.size();
+    if (c->prm.knn_backend == ICP_KNN_LBVH && c->prm.matching == ICP_MATCH_KNN) return build_bvh(c);   // buildIndex; otherwise built on first use
+    return ICP_OK;
 }
 
 int icp_set_source(icp_ctx* c, const float* xyz, const float* normals, const uint8_t* rgba, int32_t n) {

@@ -49,7 +49,7 @@ enum icp_status {
 enum { ICP_METRIC_POINT_TO_POINT = 0, ICP_METRIC_POINT_TO_PLANE = 1, ICP_METRIC_SYMMETRIC = 2 };   /* ICPOptimizer.h:46-48,131-136 */
 enum { ICP_MATCH_KNN = 0, ICP_MATCH_PROJECTIVE = 1 };                                               /* ICPOptimizer.h:71-78 */
 enum { ICP_WEIGHT_CONSTANT = 0, ICP_WEIGHT_DISTANCES = 1, ICP_WEIGHT_NORMALS = 2, ICP_WEIGHT_COLORS = 3 };   /* weighting.h:8 */
-enum { ICP_KNN_BRUTE_FORCE = 0, ICP_KNN_GRID = 1 };   /* both exact, identical (d2, lowest-index) argmin */
+enum { ICP_KNN_BRUTE_FORCE = 0, ICP_KNN_LBVH = 1 };   /* both exact: identical (d2, lowest-index) argmin, bit for bit */
 
 /* The setter surface of ICPOptimizer (ICPOptimizer.h:41-95) as one POD. */
 typedef struct icp_params {
@@ -63,7 +63,7 @@ typedef struct icp_params {
     float   max_distance;    /* setMatchingMaxDistance        default 0.0003f, squared metres */
     float   fx, fy, cx, cy;  /* setCameraParamsMatchingMethod (ICPOptimizer.h:80-82) */
     int32_t width, height;
-    int32_t knn_backend;     /* ICP_KNN_* (extension; the reference uses an approximate FLANN kd-tree) */
+    int32_t knn_backend;     /* ICP_KNN_* (extension; the reference's own index is an approximate, randomised FLANN kd-tree) */
     int32_t record_rmse;     /* 1: per-iteration RMSE against the convergence reference (ConvergenceMeasure.h:50-66) */
 } icp_params;
 

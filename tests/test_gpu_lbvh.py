@@ -1,0 +1,94 @@
+"""GPU tests of the exact LBVH k-NN backend (ICP_KNN_LBVH): bit-identical to the brute-force scan / the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+LBVH = 1
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def ctx_with(factory, t, q, thr, backend):
+    c = factory()
+    c.params.max_distance = thr; c.params.knn_backend = backend; c.push_params()
+    c.set_target(t, None, None)
+    if q is not None:
+        c.set_source(q, None, None)
+    return c
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (3, 7), (64, 8), (65, 9), (200, 1000), (1000, 4097), (5000, 33333)])
+def test_lbvh_ragged_sizes(gpu_ctx_factory, orc, n, m):
+    rng = np.random.default_rng(n * 7 + m)
+    q = rng.uniform(-2, 2, (n, 3)).astype(f32); t = rng.uniform(-2, 2, (m, 3)).astype(f32)
+    c = ctx_with(gpu_ctx_factory, t, q, 0.5, LBVH)
+    mg, dg = c.match(np.eye(4))
+    mo, do = orc.knn3(q, t, 0.5)
+    assert np.array_equal(mg["idx"], mo["idx"]) and np.array_equal(bits(dg), bits(do))
+    assert np.array_equal(c.query_matches(q)["idx"], mo["idx"])
+
+
+def test_lbvh_ties_duplicates_nonfinite(gpu_ctx_factory, orc):
+    rng = np.random.default_rng(3)
+    t = rng.uniform(-1, 1, (5000, 3)).astype(f32)
+    t[10] = np.nan; t[20] = -np.inf; t[21, 1] = np.inf
+    t[31] = t[30]; t[4000] = t[30]; t[4999] = t[0]; t[1000:1100] = t[999]              # long run of exact duplicates
+    t[100] = [5, 5, 5]; t[50] = [5, 5, 6]
+    q = rng.uniform(-1, 1, (800, 3)).astype(f32)
+    q[0] = t[30]; q[1] = np.nan; q[2, 0] = np.inf; q[3] = t[0]; q[4] = -np.inf; q[5] = [5, 5, 5.5]; q[6] = t[999]
+    q[7] = [1e6, -1e6, 1e6]; q[8] = [40, 0, 0]                                           # far outside the bounding box
+    for thr in (0.0, 1e-4, 0.05, 1e30, 3.4028235e38):
+        c = ctx_with(gpu_ctx_factory, t, q, thr, LBVH)
+        mg, dg = c.match(np.eye(4))
+        mo, do = orc.knn3(q, t, thr)
+        assert np.array_equal(mg["idx"], mo["idx"]) and np.array_equal(bits(dg), bits(do)), thr
+        assert np.array_equal(bits(mg["weight"]), bits(mo["weight"])), thr
+    assert mo["idx"][0] == 30 and mo["idx"][5] == 50 and mo["idx"][6] == 999
+
+
+def test_lbvh_degenerate_targets(gpu_ctx_factory, orc):
+    q = np.random.default_rng(1).uniform(-1, 1, (100, 3)).astype(f32)
+    for t in (np.full((50, 3), np.nan, f32),                                   # nothing finite: empty tree
+              np.tile(np.array([[0.25, -0.5, 0.125]], f32), (300, 1)),          # all points identical: zero-extent box
+              np.stack([np.linspace(-1, 1, 777), np.zeros(777), np.zeros(777)], 1).astype(f32)):   # collinear
+        c = ctx_with(gpu_ctx_factory, t, q, 10.0, LBVH)
+        mg, dg = c.match(np.eye(4))
+        mo, do = orc.knn3(q, t, 10.0)
+        assert np.array_equal(mg["idx"], mo["idx"]) and np.array_equal(bits(dg), bits(do))
+
+
+def test_lbvh_equals_brute_force_backend_on_full_pipeline(gpu_ctx_factory, bunny):
+    """Identical matches => identical sums => bit-identical poses for all three metrics (incl. multires)."""
+    for metric in (0, 1, 2):
+        poses = []
+        for backend in (0, LBVH):
+            c = gpu_ctx_factory()
+            c.params.max_distance = 0.0003; c.params.metric = metric; c.params.n_iterations = 20; c.params.multires = 1
+            c.params.knn_backend = backend; c.push_params()
+            c.set_target(bunny["tgt_pts"], bunny["tgt_nrm"]); c.set_source(bunny["src_pts"], bunny["src_nrm"])
+            pose, recs, _ = c.run(np.eye(4))
+            poses.append((pose, [r["n_valid"] for r in recs]))
+        assert np.array_equal(poses[0][0], poses[1][0]) and poses[0][1] == poses[1][1]
+
+
+def test_lbvh_fullsize_bit_exact_and_rebuild(gpu_ctx_factory, orc):
+    from icp_amd import synth
+    p = synth.eth_like_pair(1)
+    c = ctx_with(gpu_ctx_factory, p["tgt_pts"], p["src_pts"], 10.0, LBVH)
+    mg, dg = c.match(np.eye(4))
+    kd = orc.KdTree(p["tgt_pts"])
+    mo, do = kd.query(p["src_pts"], 10.0)
+    assert np.array_equal(mg["idx"], mo["idx"]) and np.array_equal(bits(dg), bits(do))
+    # a perturbed pose (larger NN distances, the first-iteration regime)
+    T = synth.make_pose((0.05, -0.04, 0.08), (0.3, -0.2, 0.1)).astype(f32)
+    mg, dg = c.match(T)
+    mo, do = kd.query(orc.transform_points(p["src_pts"], T), 10.0)
+    assert np.array_equal(mg["idx"], mo["idx"]) and np.array_equal(bits(dg), bits(do))
+    # new target on the same context: the index must be rebuilt (buildIndex per call, main.cpp:411)
+    c.set_target(p["src_unperturbed"], None, None)
+    mg, dg = c.match(np.eye(4))
+    mo, do = orc.KdTree(p["src_unperturbed"]).query(p["src_pts"], 10.0)
+    assert np.array_equal(mg["idx"], mo["idx"]) and np.array_equal(bits(dg), bits(do))
