@@ -119,6 +119,8 @@ struct KnnParams {
     icp_match_t* out; float* d2_out;                           // direct outputs (nseg == 1)
     unsigned long long* best64;                              // packed partial results (nseg > 1)
     int nseg;
+    int* nn_raw;                                             // [n] raw nearest index of this launch (BVH backend), seed of the next one
+    int use_prev;                                            // 1: nn_raw holds the previous iteration's result for the same queries
 };
 
 template <int DIM>
@@ -219,14 +221,27 @@ constexpr int BVH_LEAF = 8;
 constexpr int BVH_MAXD = 24;
 constexpr int BVH_THREADS = 128;
 
-struct BvhNode { float lo0[3], hi0[3], lo1[3], hi1[3]; float pad[4]; };   // boxes of children 2k+1 and 2k+2, 64 B
+// Internal node k: boxes of BOTH children (2k+1 -> element 0, 2k+2 -> element 1), pair-interleaved so that one
+// 64-B record feeds packed-f32 math directly ({lo0, lo1} pairs).  Leaf: 8 points SoA + original indices = 128 B.
+struct BvhNode { float lox[2], loy[2], loz[2], hix[2], hiy[2], hiz[2]; float pad[4]; };
+struct BvhLeaf { float x[8], y[8], z[8]; int idx[8]; };
 
 struct BvhView {
-    const float4* pts;      // [n_leaves * BVH_LEAF] kd-ordered points, w = original index bits; pads are +inf
+    const BvhLeaf* leaves;  // [max(n_leaves,1)] kd-ordered points, 8 per leaf; pads are +inf with index -1
     const BvhNode* nodes;   // [Lp - 1] internal nodes in heap order (node k: children 2k+1, 2k+2; leaves start at Lp-1)
     int n_valid;            // finite target points in the tree
     int Lp;                 // leaves rounded up to a power of two
 };
+
+__device__ __forceinline__ unsigned long long spread21(unsigned int v) {   // 21 bits -> every third bit
+    unsigned long long x = v & 0x1FFFFFull;
+    x = (x | (x << 32)) & 0x1F00000000FFFFull;
+    x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
 
 __device__ __forceinline__ unsigned int ordered_bits(float f) {          // monotone float -> uint map
     const unsigned int u = __float_as_uint(f);
@@ -285,40 +300,42 @@ __global__ void k_bvh_level_keys(const float* __restrict__ x, const float* __res
 __global__ void k_iota(int* p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = i; }
 
 __global__ void k_bvh_gather(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                             const int* __restrict__ sorted_idx, int n_valid, int n_slots, float4* __restrict__ pts) {
+                             const int* __restrict__ sorted_idx, int n_valid, int n_slots, BvhLeaf* __restrict__ leaves) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
-    float4 v;
-    if (i < n_valid) { const int j = sorted_idx[i]; v.x = x[j]; v.y = y[j]; v.z = z[j]; v.w = __int_as_float(j); }
-    else { v.x = INFINITY; v.y = INFINITY; v.z = INFINITY; v.w = __int_as_float(-1); }
-    pts[i] = v;
+    BvhLeaf* lf = leaves + (i / BVH_LEAF); const int t = i % BVH_LEAF;
+    if (i < n_valid) { const int j = sorted_idx[i]; lf->x[t] = x[j]; lf->y[t] = y[j]; lf->z[t] = z[j]; lf->idx[t] = j; }
+    else { lf->x[t] = INFINITY; lf->y[t] = INFINITY; lf->z[t] = INFINITY; lf->idx[t] = -1; }
 }
 
 // Boxes of the children of the internal nodes [first, first + count), bottom-up.  child_is_leaf: children are leaves.
-__device__ __forceinline__ void child_box(const float4* __restrict__ pts, const BvhNode* __restrict__ nodes, int child, int Lp, int n_leaves,
+__device__ __forceinline__ void child_box(const BvhLeaf* __restrict__ leaves, const BvhNode* __restrict__ nodes, int child, int Lp, int n_leaves,
                                           bool child_is_leaf, float* lo, float* hi) {
     lo[0] = lo[1] = lo[2] = INFINITY; hi[0] = hi[1] = hi[2] = -INFINITY;          // empty box: lower bound = +inf
     if (child_is_leaf) {
         const int leaf = child - (Lp - 1);
         if (leaf < n_leaves) {
+            const BvhLeaf lf = leaves[leaf];
             for (int k = 0; k < BVH_LEAF; k++) {
-                const float4 p = pts[(size_t)leaf * BVH_LEAF + k];
-                if (p.x < INFINITY) { lo[0] = fminf(lo[0], p.x); lo[1] = fminf(lo[1], p.y); lo[2] = fminf(lo[2], p.z); hi[0] = fmaxf(hi[0], p.x); hi[1] = fmaxf(hi[1], p.y); hi[2] = fmaxf(hi[2], p.z); }
+                if (lf.x[k] < INFINITY) { lo[0] = fminf(lo[0], lf.x[k]); lo[1] = fminf(lo[1], lf.y[k]); lo[2] = fminf(lo[2], lf.z[k]); hi[0] = fmaxf(hi[0], lf.x[k]); hi[1] = fmaxf(hi[1], lf.y[k]); hi[2] = fmaxf(hi[2], lf.z[k]); }
             }
         }
     } else {
         const BvhNode nd = nodes[child];
-#pragma unroll
-        for (int k = 0; k < 3; k++) { lo[k] = fminf(nd.lo0[k], nd.lo1[k]); hi[k] = fmaxf(nd.hi0[k], nd.hi1[k]); }
+        lo[0] = fminf(nd.lox[0], nd.lox[1]); lo[1] = fminf(nd.loy[0], nd.loy[1]); lo[2] = fminf(nd.loz[0], nd.loz[1]);
+        hi[0] = fmaxf(nd.hix[0], nd.hix[1]); hi[1] = fmaxf(nd.hiy[0], nd.hiy[1]); hi[2] = fmaxf(nd.hiz[0], nd.hiz[1]);
     }
 }
-__global__ void k_bvh_nodes(const float4* __restrict__ pts, int n_leaves, int Lp, int first, int count, int children_are_leaves, BvhNode* __restrict__ nodes) {
+__global__ void k_bvh_nodes(const BvhLeaf* __restrict__ leaves, int n_leaves, int Lp, int first, int count, int children_are_leaves, BvhNode* __restrict__ nodes) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     const int node = first + t;
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    child_box(leaves, nodes, 2 * node + 1, Lp, n_leaves, children_are_leaves != 0, lo0, hi0);
+    child_box(leaves, nodes, 2 * node + 2, Lp, n_leaves, children_are_leaves != 0, lo1, hi1);
     BvhNode out;
-    child_box(pts, nodes, 2 * node + 1, Lp, n_leaves, children_are_leaves != 0, out.lo0, out.hi0);
-    child_box(pts, nodes, 2 * node + 2, Lp, n_leaves, children_are_leaves != 0, out.lo1, out.hi1);
+    out.lox[0] = lo0[0]; out.lox[1] = lo1[0]; out.loy[0] = lo0[1]; out.loy[1] = lo1[1]; out.loz[0] = lo0[2]; out.loz[1] = lo1[2];
+    out.hix[0] = hi0[0]; out.hix[1] = hi1[0]; out.hiy[0] = hi0[1]; out.hiy[1] = hi1[1]; out.hiz[0] = hi0[2]; out.hiz[1] = hi1[2];
     out.pad[0] = out.pad[1] = out.pad[2] = out.pad[3] = 0.f;
     nodes[node] = out;
 }
@@ -331,69 +348,283 @@ __device__ __forceinline__ float box_lb(const float* lo, const float* hi, float 
     return (ex * ex + ey * ey) + ez * ez;
 }
 
-__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, const BvhView bv) {
-    __shared__ int st_node[BVH_MAXD][BVH_THREADS];
-    __shared__ float st_lb[BVH_MAXD][BVH_THREADS];
+// Lower bounds of both children at once (packed f32): same op order as the point distance, see box_lb.
+__device__ __forceinline__ f2 pair_lb(const f2 lox, const f2 loy, const f2 loz, const f2 hix, const f2 hiy, const f2 hiz, const f2 px2, const f2 py2, const f2 pz2) {
+    const f2 ax = lox - px2, bx = px2 - hix, ay = loy - py2, by = py2 - hiy, az = loz - pz2, bz = pz2 - hiz;
+    const f2 ex = {fmaxf(fmaxf(ax.x, bx.x), 0.f), fmaxf(fmaxf(ax.y, bx.y), 0.f)};
+    const f2 ey = {fmaxf(fmaxf(ay.x, by.x), 0.f), fmaxf(fmaxf(ay.y, by.y), 0.f)};
+    const f2 ez = {fmaxf(fmaxf(az.x, bz.x), 0.f), fmaxf(fmaxf(az.y, bz.y), 0.f)};
+    return (ex * ex + ey * ey) + ez * ez;
+}
+
+// Evaluate the 8 points of a leaf against the lane's query; exact lexicographic (d2, lowest index) update.
+// `wave_uniform_leaf`: the leaf pointer is wave-uniform (packet traversal) -> its 128 B arrive through scalar loads and
+// the update pass is skipped for the whole wave unless some lane ties or improves.
+template <bool wave_uniform_leaf>
+__device__ __forceinline__ void leaf_eval(const BvhLeaf* __restrict__ lf, const f2 px2, const f2 py2, const f2 pz2, float& best, int& bi) {
+    float dd[BVH_LEAF];
+    float m = FLT_MAX;
+#pragma unroll
+    for (int t = 0; t < BVH_LEAF; t += 2) {
+        const f2 qx = *(const f2*)(&lf->x[t]), qy = *(const f2*)(&lf->y[t]), qz = *(const f2*)(&lf->z[t]);
+        const f2 dx = px2 - qx, dy = py2 - qy, dz = pz2 - qz;
+        const f2 d = (dx * dx + dy * dy) + dz * dz;
+        dd[t] = d.x; dd[t + 1] = d.y;
+        m = fminf(fminf(m, d.x), d.y);
+    }
+    const bool hit = m <= best;          // something in this leaf ties or beats the running best
+    if (wave_uniform_leaf ? (__ballot(hit) != 0ull) : hit) {
+#pragma unroll
+        for (int t = 0; t < BVH_LEAF; t++) {
+            const int j = lf->idx[t];
+            const bool take = (dd[t] < best) | ((dd[t] == best) & (j < bi));     // first minimum = lowest original index
+            best = take ? dd[t] : best; bi = take ? j : bi;
+        }
+    }
+}
+
+// Temporal seeding: ICP moves the queries a little per iteration, so the previous iteration's neighbour j0 is a
+// good first candidate.  The traversal starts with (best, bi) = (d2(p, target[j0]), j0) -- a real candidate evaluated
+// with the same fp32 formula -- and the final (d2, index) is still the exact lexicographic minimum over ALL targets
+// (a box is skipped only if its lower bound exceeds the running best).
+__device__ __forceinline__ void seed_from_previous(const KnnParams& kp, int k, float px, float py, float pz, float& best, int& bi) {
+    if (!kp.use_prev) return;
+    const int j0 = kp.nn_raw[k];
+    if (j0 < 0) return;
+    const float dx = px - kp.tx[j0], dy = py - kp.ty[j0], dz = pz - kp.tz[j0];
+    const float d = (dx * dx + dy * dy) + dz * dz;
+    if (d < best) { best = d; bi = j0; }
+}
+
+// Per-lane traversal: every lane walks the tree on its own (per-lane stack in LDS).  Used for one-shot queries
+// (icp_query_matches) whose order is arbitrary.
+// XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (block b runs on the XCD group b % 8), each
+// with a private 4 MiB L2.  With Morton-sorted queries, giving every XCD group ONE contiguous slice of the sorted list
+// means its L2 only has to hold the part of the tree under that slice (plus the shared top levels) instead of all of it.
+__device__ __forceinline__ int xcd_contiguous_block(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = b & 7, j = b >> 3;        // XCD group x owns q (+1 if x < r) consecutive logical blocks
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// Per-lane traversal state of the complete binary tree in heap order: three registers -- depth, index within the level
+// and a bit mask of the levels whose far sibling is still pending.  The only per-level storage is the far sibling's
+// lower bound, kept as a 16-bit truncated (never larger, hence conservative) value in LDS: 2 B x depth per lane, which
+// leaves room for the full 32 waves per CU.
+struct TravState { int depth; int idx; unsigned int pending; bool alive; };
+
+__device__ __forceinline__ void trav_pop(TravState& st, const unsigned short* __restrict__ lb16, int tid, int nthreads, float best) {
+    while (!st.alive && st.pending) {                     // deepest pending sibling that survives the (possibly improved) bound
+        const int d = 31 - __clz((int)st.pending);
+        st.pending &= ~(1u << d);
+        const float lb = __uint_as_float((unsigned int)lb16[d * nthreads + tid] << 16);      // <= true bound
+        if (!(lb * 0.99999f > best)) { st.idx = (st.idx >> (st.depth - d - 1)) ^ 1; st.depth = d + 1; st.alive = true; }
+    }
+}
+
+// Runs the "near child first" traversal until it finishes or `budget` node/leaf visits are spent.
+// "while-while" shape: busy lanes first descend through internal nodes, then evaluate their leaves together.
+__device__ __forceinline__ void trav_run(const BvhView& bv, int tree_depth, const f2 px2, const f2 py2, const f2 pz2, TravState& st,
+                                         float& best, int& bi, unsigned short* __restrict__ lb16, int tid, int nthreads, int budget) {
+    int steps = 0;
+    while (st.alive && steps < budget) {
+        while (st.alive && st.depth < tree_depth && steps < budget) {
+            const BvhNode* __restrict__ nd = bv.nodes + ((1 << st.depth) - 1 + st.idx);
+            const f2 l = pair_lb(*(const f2*)nd->lox, *(const f2*)nd->loy, *(const f2*)nd->loz, *(const f2*)nd->hix, *(const f2*)nd->hiy, *(const f2*)nd->hiz, px2, py2, pz2);
+            const bool swap = l.y < l.x;                  // child 1 is nearer
+            const float ln = swap ? l.y : l.x, lf = swap ? l.x : l.y;
+            const bool take_near = !(ln * 0.99999f > best), take_far = !(lf * 0.99999f > best);
+            if (take_near) {
+                if (take_far) { lb16[st.depth * nthreads + tid] = (unsigned short)(__float_as_uint(lf) >> 16); st.pending |= 1u << st.depth; }
+                st.idx = 2 * st.idx + (swap ? 1 : 0); st.depth++;
+            } else st.alive = false;                      // both children pruned (lf >= ln)
+            trav_pop(st, lb16, tid, nthreads, best);
+            steps++;
+        }
+        if (st.alive && st.depth == tree_depth && steps < budget) {
+            leaf_eval<false>(bv.leaves + st.idx, px2, py2, pz2, best, bi);
+            st.alive = false;
+            trav_pop(st, lb16, tid, nthreads, best);
+            steps++;
+        }
+    }
+}
+
+// Phase 1: every lane walks the tree on its own for its own query.  The kernel is bound by dependent-load latency (one
+// 64-B node record per step), so what moves it is occupancy, L2 locality (Morton-sorted queries, XCD-contiguous slices)
+// and -- above all -- the TAIL: a query whose neighbour is far away (non-overlapping part of the scans) has to open every
+// leaf that intersects its large search ball, hundreds of serial steps for one lane while the rest of the chip idles.
+// Such a query stops after BVH_BUDGET visits, parks its running best as a seed and is queued for k_knn_heavy, where a
+// whole wave finishes it cooperatively.
+constexpr int BVH_BUDGET = 96;
+
+struct HeavyQueue { int* list; int* count; int capacity; };
+
+__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, const BvhView bv, const int* __restrict__ qorder, int tree_depth, const HeavyQueue hq) {
+    extern __shared__ unsigned short bvh_lb16[];          // [tree_depth + 1][BVH_THREADS]
     const int tid = threadIdx.x;
-    const int k = blockIdx.x * BVH_THREADS + tid;
-    if (k >= kp.n) return;
+    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS + tid;
+    if (t >= kp.n) return;
+    const int k = qorder ? qorder[t] : t;                 // spatially sorted queries: neighbouring lanes walk similar paths
     const int i = kp.sel ? kp.sel[k] : k;
     float px = kp.sx[i], py = kp.sy[i], pz = kp.sz[i];
     if (!kp.pretransformed) { float a, b, c; xform_point(kp.ps->pose, px, py, pz, a, b, c); px = a; py = b; pz = c; }
     float best = FLT_MAX; int bi = -1;
-#ifdef ICP_BVH_STATS
-    int n_nodes_v = 0, n_leaves_v = 0;
-#endif
     if (finite3(px, py, pz) && bv.n_valid > 0) {
-        const int first_leaf = bv.Lp - 1;
-        int sp = 0, node = 0;
-        while (true) {
-            if (node >= first_leaf) {
-#ifdef ICP_BVH_STATS
-                n_leaves_v++;
-#endif
-                const float4* __restrict__ lp = bv.pts + (size_t)(node - first_leaf) * BVH_LEAF;
-#pragma unroll
-                for (int t = 0; t < BVH_LEAF; t++) {
-                    const float4 q = lp[t];
-                    const float dx = px - q.x, dy = py - q.y, dz = pz - q.z;
-                    const float d = (dx * dx + dy * dy) + dz * dz;
-                    const int j = __float_as_int(q.w);
-                    if (d < best || (d == best && j < bi)) { best = d; bi = j; }      // first minimum = lowest original index
-                }
-            } else {
-#ifdef ICP_BVH_STATS
-                n_nodes_v++;
-#endif
-                const BvhNode nd = bv.nodes[node];
-                const int c0 = 2 * node + 1;
-                const float l0 = box_lb(nd.lo0, nd.hi0, px, py, pz);
-                const float l1 = box_lb(nd.lo1, nd.hi1, px, py, pz);
-                const bool swap = l1 < l0;
-                const int nearc = swap ? c0 + 1 : c0, farc = swap ? c0 : c0 + 1;
-                const float ln = swap ? l1 : l0, lf = swap ? l0 : l1;
-                if (!(ln * 0.99999f > best)) {
-                    if (!(lf * 0.99999f > best)) { st_node[sp][tid] = farc; st_lb[sp][tid] = lf; sp++; }
-                    node = nearc;
-                    continue;
-                }
+        seed_from_previous(kp, k, px, py, pz, best, bi);
+        const f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz};
+        TravState st; st.depth = 0; st.idx = 0; st.pending = 0u; st.alive = true;
+        trav_run(bv, tree_depth, px2, py2, pz2, st, best, bi, bvh_lb16, tid, BVH_THREADS, hq.list ? BVH_BUDGET : 0x7fffffff);
+        if (st.alive) {                                   // over budget: park (best, bi) as the seed and hand over to k_knn_heavy
+            const int slot = atomicAdd(hq.count, 1);
+            if (slot < hq.capacity) {
+                hq.list[slot] = k;
+                kp.nn_raw[k] = bi; kp.d2_out[k] = best;
+                return;
             }
-            bool found = false;
-            while (sp > 0) {
-                --sp;
-                if (!(st_lb[sp][tid] * 0.99999f > best)) { node = st_node[sp][tid]; found = true; break; }
-            }
-            if (!found) break;
+            trav_run(bv, tree_depth, px2, py2, pz2, st, best, bi, bvh_lb16, tid, BVH_THREADS, 0x7fffffff);     // queue full: finish here
         }
     }
+    if (kp.nn_raw) kp.nn_raw[k] = bi;
     icp_match_t m;
     if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
     kp.out[k] = m;
-#ifdef ICP_BVH_STATS
-    if (kp.d2_out) kp.d2_out[k] = (float)(n_nodes_v + 4096 * n_leaves_v);
-#else
     if (kp.d2_out) kp.d2_out[k] = best;
+}
+
+// Phase 2: one WAVE per parked query.  The 64 lanes start at the 64 subtrees of depth 6 (fewer in a small tree), walk
+// them independently in short bursts and share the running best after every burst (lexicographic (d2, index) wave
+// minimum), so every lane prunes against the best candidate any lane has found.  The union of the subtrees is the whole
+// tree and every bound used for pruning is the distance of a real candidate => the result is the exact argmin.
+constexpr int HEAVY_WAVES = 4;
+__global__ __launch_bounds__(HEAVY_WAVES * WAVE) void k_knn_heavy(const KnnParams kp, const BvhView bv, int tree_depth, const HeavyQueue hq) {
+    extern __shared__ unsigned short bvh_lb16[];          // [tree_depth + 1][HEAVY_WAVES * WAVE]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int gw = blockIdx.x * HEAVY_WAVES + (tid >> 6), nw = gridDim.x * HEAVY_WAVES;
+    const int count = min(*hq.count, hq.capacity);
+    const int S = min(6, tree_depth);
+    for (int h = gw; h < count; h += nw) {
+        const int k = hq.list[h];
+        const int i = kp.sel ? kp.sel[k] : k;
+        float px = kp.sx[i], py = kp.sy[i], pz = kp.sz[i];
+        if (!kp.pretransformed) { float a, b, c; xform_point(kp.ps->pose, px, py, pz, a, b, c); px = a; py = b; pz = c; }
+        const f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz};
+        float best = kp.d2_out[k]; int bi = kp.nn_raw[k];     // seed parked by phase 1
+        TravState st; st.depth = S; st.idx = lane; st.pending = 0u; st.alive = lane < (1 << S);
+        if (st.alive && S > 0) {                              // bound of the lane's own subtree from its parent's record
+            const BvhNode* __restrict__ nd = bv.nodes + ((1 << (S - 1)) - 1 + (lane >> 1));
+            const f2 l = pair_lb(*(const f2*)nd->lox, *(const f2*)nd->loy, *(const f2*)nd->loz, *(const f2*)nd->hix, *(const f2*)nd->hiy, *(const f2*)nd->hiz, px2, py2, pz2);
+            const float lb = (lane & 1) ? l.y : l.x;
+            st.alive = !(lb * 0.99999f > best);
+        }
+        while (__ballot(st.alive) != 0ull) {
+            trav_run(bv, tree_depth, px2, py2, pz2, st, best, bi, bvh_lb16, tid, HEAVY_WAVES * WAVE, 8);
+            // share the best candidate: lexicographic (d2, index) minimum over the wave
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float od = __shfl_xor(best, off, WAVE); const int oi = __shfl_xor(bi, off, WAVE);
+                const bool take = (od < best) | ((od == best) & (oi < bi) & (oi >= 0)) | ((od == best) & (bi < 0) & (oi >= 0));
+                best = take ? od : best; bi = take ? oi : bi;
+            }
+            if (!st.alive) trav_pop(st, bvh_lb16, tid, HEAVY_WAVES * WAVE, best);     // (no-op: pop already ran; keeps the state consistent)
+        }
+        if (lane == 0) {
+            kp.nn_raw[k] = bi;
+            icp_match_t m;
+            if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
+            kp.out[k] = m;
+            kp.d2_out[k] = best;
+        }
+    }
+}
+
+// Packet traversal: the 64 lanes of a wave are 64 spatially adjacent queries (qorder = Morton order of the source) and
+// walk the tree TOGETHER.  The current node is wave-uniform, so node records and leaves arrive through scalar loads
+// (SGPR operands of the packed-f32 math), the node stack is one scalar stack per wave and all control flow is scalar --
+// no exec-mask divergence and no per-lane stack traffic except one lower-bound word per push.  A subtree is entered if ANY lane
+// still needs it; every lane evaluates every leaf the packet opens (extra candidates never hurt exactness) and keeps
+// its own running best, so each lane's result is the exact lexicographic minimum.
+constexpr int PK_WAVES = 4;
+__global__ __launch_bounds__(PK_WAVES * WAVE) void k_knn_packet(const KnnParams kp, const BvhView bv, const int* __restrict__ qorder) {
+    __shared__ float st_lb[PK_WAVES][BVH_MAXD][WAVE];
+    __shared__ int st_node[PK_WAVES][BVH_MAXD];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = (blockIdx.x * PK_WAVES + w) * WAVE + lane;
+    const bool act = t < kp.n;
+    const int k = act ? (qorder ? qorder[t] : t) : 0;
+    const int i = kp.sel ? kp.sel[k] : k;
+    float px = kp.sx[i], py = kp.sy[i], pz = kp.sz[i];
+    if (!kp.pretransformed) { float a, b, c; xform_point(kp.ps->pose, px, py, pz, a, b, c); px = a; py = b; pz = c; }
+    const bool live = act && finite3(px, py, pz) && bv.n_valid > 0;
+    float best = FLT_MAX; int bi = -1;
+    if (live) seed_from_previous(kp, k, px, py, pz, best, bi);
+    if (!live) best = -1.f;                              // never needs a node, never takes a candidate
+    if (__ballot(live) != 0ull) {
+        const f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz};
+        const int first_leaf = bv.Lp - 1;
+        int sp = 0, node = 0;                            // wave-uniform
+#ifdef ICP_BVH_STATS
+        int n_nodes_v = 0, n_leaves_v = 0;
 #endif
+        while (node >= 0) {
+            node = __builtin_amdgcn_readfirstlane(node);  // (already uniform: tells the compiler so -> scalar loads, scalar branches)
+#ifdef ICP_BVH_STATS
+            if (node >= first_leaf) n_leaves_v++; else n_nodes_v++;
+#endif
+            if (node >= first_leaf) {
+                leaf_eval<true>(bv.leaves + (node - first_leaf), px2, py2, pz2, best, bi);
+                node = -1;
+            } else {
+                const BvhNode* __restrict__ nd = bv.nodes + node;     // uniform address -> s_load_dwordx16
+                const f2 l = pair_lb(*(const f2*)nd->lox, *(const f2*)nd->loy, *(const f2*)nd->loz, *(const f2*)nd->hix, *(const f2*)nd->hiy, *(const f2*)nd->hiz, px2, py2, pz2);
+                const bool need0 = !(l.x * 0.99999f > best), need1 = !(l.y * 0.99999f > best);
+                const unsigned long long b0 = __ballot(need0), b1 = __ballot(need1);
+                const int c0 = 2 * node + 1;
+                if ((b0 | b1) == 0ull) node = -1;
+                else if (b1 == 0ull) node = c0;
+                else if (b0 == 0ull) node = c0 + 1;
+                else {
+                    // both subtrees are needed by someone: descend into the one most lanes are closer to, keep the other
+                    const unsigned long long p1 = __ballot((need0 | need1) & (l.y < l.x));
+                    const int n1 = __popcll(p1), nall = __popcll(b0 | b1);
+                    const bool first1 = 2 * n1 > nall;
+                    st_lb[w][sp][lane] = first1 ? l.x : l.y;
+                    if (lane == 0) st_node[w][sp] = first1 ? c0 : c0 + 1;
+                    sp++;
+                    node = first1 ? c0 + 1 : c0;
+                }
+            }
+            while (node < 0 && sp > 0) {                 // pop until some lane still needs the entry
+                --sp;
+                if (__ballot(!(st_lb[w][sp][lane] * 0.99999f > best)) != 0ull) node = __builtin_amdgcn_readfirstlane(st_node[w][sp]);
+            }
+        }
+#ifdef ICP_BVH_STATS
+        if (live) best = (float)(n_nodes_v + 4096 * n_leaves_v);
+#endif
+    }
+    if (!act) return;
+    if (!live) { best = FLT_MAX; bi = -1; }
+    if (kp.nn_raw) kp.nn_raw[k] = bi;
+    icp_match_t m;
+    if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
+    kp.out[k] = m;
+    if (kp.d2_out) kp.d2_out[k] = best;
+}
+
+// Morton key of the (untransformed) query points -> spatially coherent wave packets for k_knn_packet.
+__global__ void k_query_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const int* __restrict__ sel, int n,
+                             float lox, float loy, float loz, float sx, float sy, float sz, unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int i = sel ? sel[t] : t;
+    const float a = x[i], b = y[i], c = z[i];
+    unsigned long long key = ~0ull;
+    if (finite3(a, b, c)) {
+        const float fa = fminf(fmaxf((a - lox) * sx, 0.f), 2097151.f), fb = fminf(fmaxf((b - loy) * sy, 0.f), 2097151.f), fc = fminf(fmaxf((c - loz) * sz, 0.f), 2097151.f);
+        key = spread21((unsigned int)fa) | (spread21((unsigned int)fb) << 1) | (spread21((unsigned int)fc) << 2);
+    }
+    keys[t] = key; vals[t] = t;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -6,6 +6,7 @@
 // =====================================================================================
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include "icp_device.hpp"
 #include <rocprim/device/device_radix_sort.hpp>
@@ -41,13 +42,13 @@ struct Cloud {
     bool has_normals = false, has_colors = false;
 };
 
-struct Level { DevBuf idx; int n = 0; };
+struct Level { DevBuf idx; DevBuf order; int n = 0; };   // selection (original indices) + Morton order of its positions
 
 // LBVH over the target (buildIndex): device buffers + the host-side facts needed to launch the build.
 struct Bvh {
     bool valid = false;
     int n_valid = 0, n_leaves = 0, Lp = 1;
-    DevBuf keys, keys2, vals, vals2, temp, pts, nodes, lvl;
+    DevBuf keys, keys2, vals, vals2, temp, leaves, nodes, lvl;
     std::vector<int> finite_idx;                     // indices of the finite target points, increasing
     double build_ms = 0.0;
 };
@@ -62,8 +63,10 @@ struct icp_ctx {
     Cloud tgt, src, qry;                 // qry: scratch cloud of icp_query_matches
     Bvh bvh;                             // exact LBVH index of the target (knn_backend == ICP_KNN_LBVH)
     std::vector<uint8_t> src_valid;      // host mask: finite point && finite normal (PointCloud.h:334)
+    float src_lo[3] = {0, 0, 0}, src_hi[3] = {0, 0, 0};   // bounding box of the finite source points
+    DevBuf order_full, okeys, okeys2, ovals, otemp; bool order_full_valid = false;   // Morton order of the full source
     std::map<int, Level> levels;         // multires selections by decimation factor
-    DevBuf ps, matches, d2, best64, partials, sums, stats, staging, rmse_partials, rmse_out;
+    DevBuf ps, matches, d2, best64, nn_raw, heavy, partials, sums, stats, staging, rmse_partials, rmse_out;
     Cloud conv_src, conv_ref; int conv_n = 0;
     float cos_reject = 0.5f;
     std::vector<hipEvent_t> events;
@@ -155,12 +158,41 @@ int write_pose(icp_ctx* c, const float pose[16]) {
     return ICP_OK;
 }
 
-struct QuerySet { const Cloud* cl; const int* sel; int n; int pretransformed; bool use_colors; };
+struct QuerySet { const Cloud* cl; const int* sel; int n; int pretransformed; bool use_colors; bool seed_prev; const int* order; };
 
 int ensure_match_buffers(icp_ctx* c, int n) {
     int rc;
     if ((rc = ensure(c, c->matches, (size_t)n * sizeof(icp_match_t)))) return rc;
     if ((rc = ensure(c, c->d2, (size_t)n * 4))) return rc;
+    return ICP_OK;
+}
+
+// Morton order of the query positions [0, n) of a selection (sel == nullptr: the full source): out[t] = position.
+int build_query_order(icp_ctx* c, const int* d_sel, int n, DevBuf& out) {
+    int rc;
+    if ((rc = ensure(c, c->okeys, (size_t)n * 8))) return rc;
+    if ((rc = ensure(c, c->okeys2, (size_t)n * 8))) return rc;
+    if ((rc = ensure(c, c->ovals, (size_t)n * 4))) return rc;
+    if ((rc = ensure(c, out, (size_t)n * 4))) return rc;
+    float sc[3];
+    for (int k = 0; k < 3; k++) { const float ext = c->src_hi[k] - c->src_lo[k]; sc[k] = (ext > 0.f && std::isfinite(ext)) ? 2097151.f / ext : 0.f; }
+    hipLaunchKernelGGL(k_query_keys, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->src.x.as<float>(), c->src.y.as<float>(), c->src.z.as<float>(), d_sel, n,
+                       c->src_lo[0], c->src_lo[1], c->src_lo[2], sc[0], sc[1], sc[2], c->okeys.as<unsigned long long>(), c->ovals.as<int>());
+    size_t temp_bytes = 0;
+    HIPCK(c, rocprim::radix_sort_pairs(nullptr, temp_bytes, c->okeys.as<unsigned long long>(), c->okeys2.as<unsigned long long>(), c->ovals.as<int>(), out.as<int>(), (size_t)n, 0, 64, c->stream));
+    if ((rc = ensure(c, c->otemp, temp_bytes))) return rc;
+    HIPCK(c, rocprim::radix_sort_pairs(c->otemp.p, temp_bytes, c->okeys.as<unsigned long long>(), c->okeys2.as<unsigned long long>(), c->ovals.as<int>(), out.as<int>(), (size_t)n, 0, 64, c->stream));
+    HIPCK(c, hipGetLastError());
+    return ICP_OK;
+}
+
+// Morton order of the whole resident source (packet traversal), built lazily; nullptr when the packet kernel is not in use.
+int get_full_order(icp_ctx* c, const int** out) {
+    *out = nullptr;
+    const icp_params& p = c->prm;
+    if (!(p.matching == ICP_MATCH_KNN && p.knn_backend == ICP_KNN_LBVH && !p.color_icp) || c->src.n <= 0) return ICP_OK;
+    if (!c->order_full_valid) { int rc; if ((rc = build_query_order(c, nullptr, c->src.n, c->order_full))) return rc; c->order_full_valid = true; }
+    *out = c->order_full.as<int>();
     return ICP_OK;
 }
 
@@ -182,7 +214,7 @@ int build_bvh(icp_ctx* c) {
     if ((rc = ensure(c, b.keys2, (size_t)cap * 8))) return rc;
     if ((rc = ensure(c, b.vals, (size_t)cap * 4))) return rc;
     if ((rc = ensure(c, b.vals2, (size_t)cap * 4))) return rc;
-    if ((rc = ensure(c, b.pts, (size_t)n_slots * 16))) return rc;
+    if ((rc = ensure(c, b.leaves, (size_t)(n_slots / BVH_LEAF) * sizeof(BvhLeaf)))) return rc;
     if ((rc = ensure(c, b.nodes, (size_t)(n_inner > 0 ? n_inner : 1) * sizeof(BvhNode)))) return rc;
     if ((rc = ensure(c, b.lvl, (size_t)(b.Lp > 1 ? b.Lp / 2 : 1) * 6 * 4))) return rc;
     const float* tx = c->tgt.x.as<float>(); const float* ty = c->tgt.y.as<float>(); const float* tz = c->tgt.z.as<float>();
@@ -205,10 +237,10 @@ int build_bvh(icp_ctx* c) {
             int* t = perm; perm = perm2; perm2 = t;
         }
     }
-    hipLaunchKernelGGL(k_bvh_gather, dim3((n_slots + 255) / 256), dim3(256), 0, c->stream, tx, ty, tz, perm, nv, n_slots, b.pts.as<float4>());
+    hipLaunchKernelGGL(k_bvh_gather, dim3((n_slots + 255) / 256), dim3(256), 0, c->stream, tx, ty, tz, perm, nv, n_slots, b.leaves.as<BvhLeaf>());
     for (int d = depth - 1; d >= 0; d--) {
         const int count = 1 << d, first = count - 1;
-        hipLaunchKernelGGL(k_bvh_nodes, dim3((count + 255) / 256), dim3(256), 0, c->stream, b.pts.as<float4>(), b.n_leaves, b.Lp, first, count,
+        hipLaunchKernelGGL(k_bvh_nodes, dim3((count + 255) / 256), dim3(256), 0, c->stream, b.leaves.as<BvhLeaf>(), b.n_leaves, b.Lp, first, count,
                            d == depth - 1 ? 1 : 0, b.nodes.as<BvhNode>());
     }
     HIPCK(c, hipGetLastError());
@@ -243,13 +275,29 @@ int launch_match(icp_ctx* c, const QuerySet& q) {
     kp.tx = c->tgt.x.as<float>(); kp.ty = c->tgt.y.as<float>(); kp.tz = c->tgt.z.as<float>();
     kp.tcr = c->tgt.cr.as<float>(); kp.tcg = c->tgt.cg.as<float>(); kp.tcb = c->tgt.cb.as<float>();
     kp.mpad = c->tgt.npad; kp.ps = c->ps.as<PoseState>(); kp.pretransformed = q.pretransformed; kp.max_dist = p.max_distance;
-    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr;
+    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0;
     if (p.knn_backend == ICP_KNN_LBVH && !q.use_colors) {
         if (!c->bvh.valid && (rc = build_bvh(c))) return rc;
-        BvhView bv; bv.pts = c->bvh.pts.as<float4>(); bv.nodes = c->bvh.nodes.as<BvhNode>();
+        BvhView bv; bv.leaves = c->bvh.leaves.as<BvhLeaf>(); bv.nodes = c->bvh.nodes.as<BvhNode>();
         bv.n_valid = c->bvh.n_valid; bv.Lp = c->bvh.Lp;
         kp.nseg = 1;
-        hipLaunchKernelGGL(k_knn_bvh, dim3((q.n + BVH_THREADS - 1) / BVH_THREADS), dim3(BVH_THREADS), 0, c->stream, kp, bv);
+        if ((rc = ensure(c, c->nn_raw, (size_t)q.n * 4))) return rc;
+        kp.nn_raw = c->nn_raw.as<int>(); kp.use_prev = q.seed_prev ? 1 : 0;
+        static const int use_packet = getenv("ICP_HIP_PACKET") ? atoi(getenv("ICP_HIP_PACKET")) : 0;
+        if (q.order && use_packet)
+            hipLaunchKernelGGL(k_knn_packet, dim3((q.n + PK_WAVES * WAVE - 1) / (PK_WAVES * WAVE)), dim3(PK_WAVES * WAVE), 0, c->stream, kp, bv, q.order);
+        else
+        {
+            int depth = 0; while ((1 << depth) < c->bvh.Lp) depth++;              // internal levels 0 .. depth-1, leaves at depth
+            const int cap = q.n < 65536 ? q.n : 65536;
+            if ((rc = ensure(c, c->heavy, (size_t)(cap + 64) * 4))) return rc;
+            HeavyQueue hq; hq.count = c->heavy.as<int>(); hq.list = hq.count + 64; hq.capacity = cap;
+            HIPCK(c, hipMemsetAsync(hq.count, 0, 4, c->stream));
+            hipLaunchKernelGGL(k_knn_bvh, dim3((q.n + BVH_THREADS - 1) / BVH_THREADS), dim3(BVH_THREADS), (size_t)(depth + 1) * BVH_THREADS * 2, c->stream,
+                               kp, bv, q.order, depth, hq);
+            int hb = (cap + HEAVY_WAVES - 1) / HEAVY_WAVES; if (hb > 512) hb = 512;
+            hipLaunchKernelGGL(k_knn_heavy, dim3(hb), dim3(HEAVY_WAVES * WAVE), (size_t)(depth + 1) * HEAVY_WAVES * WAVE * 2, c->stream, kp, bv, depth, hq);
+        }
         HIPCK(c, hipGetLastError());
         return ICP_OK;
     }
@@ -327,7 +375,7 @@ int check_ready(icp_ctx* c, bool need_source, bool full_pipeline) {
 }
 
 // Selection for a decimation factor: PointCloud::getCoarseResolution (PointCloud.h:325-343).
-int get_level(icp_ctx* c, int factor, const int** d_idx, int* n_out) {
+int get_level(icp_ctx* c, int factor, const int** d_idx, int* n_out, const int** d_order) {
     auto it = c->levels.find(factor);
     if (it == c->levels.end()) {
         std::vector<int> idx;
@@ -340,6 +388,13 @@ int get_level(icp_ctx* c, int factor, const int** d_idx, int* n_out) {
         it = c->levels.emplace(factor, lv).first;
     }
     *d_idx = it->second.idx.as<int>(); *n_out = it->second.n;
+    if (d_order) {
+        *d_order = nullptr;
+        if (it->second.n > 0) {
+            if (!it->second.order.p) { int rc; if ((rc = build_query_order(c, it->second.idx.as<int>(), it->second.n, it->second.order))) return rc; }
+            *d_order = it->second.order.as<int>();
+        }
+    }
     return ICP_OK;
 }
 
@@ -393,9 +448,9 @@ int icp_ctx_destroy(icp_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release(c->tgt); release(c->src); release(c->qry); release(c->conv_src); release(c->conv_ref);
-    release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.pts); release(c->bvh.nodes); release(c->bvh.lvl);
-    for (auto& kv : c->levels) release(kv.second.idx);
-    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->partials); release(c->sums);
+    release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->order_full); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl);
+    for (auto& kv : c->levels) { release(kv.second.idx); release(kv.second.order); }
+    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->heavy); release(c->partials); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -438,13 +493,16 @@ int icp_set_source(icp_ctx* c, const float* xyz, const float* normals, const uin
     if ((rc = set_device(c))) return rc;
     if ((rc = upload_cloud(c, c->src, xyz, normals, rgba, n, false))) return rc;
     c->src_valid.assign((size_t)n, 0);
+    for (int k = 0; k < 3; k++) { c->src_lo[k] = INFINITY; c->src_hi[k] = -INFINITY; }
     for (int i = 0; i < n; i++) {
         bool ok = std::isfinite(xyz[(size_t)i * 3]) && std::isfinite(xyz[(size_t)i * 3 + 1]) && std::isfinite(xyz[(size_t)i * 3 + 2]);
+        if (ok) for (int k = 0; k < 3; k++) { const float v = xyz[(size_t)i * 3 + k]; if (v < c->src_lo[k]) c->src_lo[k] = v; if (v > c->src_hi[k]) c->src_hi[k] = v; }
         if (ok && normals) ok = std::isfinite(normals[(size_t)i * 3]) && std::isfinite(normals[(size_t)i * 3 + 1]) && std::isfinite(normals[(size_t)i * 3 + 2]);
         c->src_valid[i] = ok ? 1 : 0;
     }
-    for (auto& kv : c->levels) release(kv.second.idx);
+    for (auto& kv : c->levels) { release(kv.second.idx); release(kv.second.order); }
     c->levels.clear();
+    c->order_full_valid = false;
     return ICP_OK;
 }
 
@@ -459,7 +517,7 @@ int icp_query_matches(icp_ctx* c, const float* transformed_xyz, const uint8_t* r
         return ICP_ERR_COLOR_MISMATCH;
     }
     if ((rc = upload_cloud(c, c->qry, transformed_xyz, nullptr, rgba, n, false))) return rc;
-    QuerySet q{&c->qry, nullptr, n, 1, colors && c->prm.matching == ICP_MATCH_KNN};
+    QuerySet q{&c->qry, nullptr, n, 1, colors && c->prm.matching == ICP_MATCH_KNN, false, nullptr};
     if ((rc = launch_match(c, q))) return rc;
     HIPCK(c, hipMemcpyAsync(out, c->matches.p, (size_t)n * sizeof(icp_match_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -472,7 +530,9 @@ int icp_match(icp_ctx* c, const float pose[16], icp_match_t* out, float* d2_out)
     if ((rc = set_device(c))) return rc;
     if ((rc = check_ready(c, true, false))) return rc;
     if ((rc = write_pose(c, pose))) return rc;
-    QuerySet q{&c->src, nullptr, c->src.n, 0, c->prm.color_icp != 0 && c->prm.matching == ICP_MATCH_KNN};
+    const int* full_order = nullptr;
+    if ((rc = get_full_order(c, &full_order))) return rc;
+    QuerySet q{&c->src, nullptr, c->src.n, 0, c->prm.color_icp != 0 && c->prm.matching == ICP_MATCH_KNN, false, full_order};
     if ((rc = launch_match(c, q))) return rc;
     HIPCK(c, hipMemcpyAsync(out, c->matches.p, (size_t)q.n * sizeof(icp_match_t), hipMemcpyDeviceToHost, c->stream));
     if (d2_out) HIPCK(c, hipMemcpyAsync(d2_out, c->d2.p, (size_t)q.n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -486,7 +546,9 @@ int icp_correspond(icp_ctx* c, const float pose[16], icp_match_t* out, double* s
     if ((rc = set_device(c))) return rc;
     if ((rc = check_ready(c, true, true))) return rc;
     if ((rc = write_pose(c, pose))) return rc;
-    QuerySet q{&c->src, nullptr, c->src.n, 0, c->prm.color_icp != 0 && c->prm.matching == ICP_MATCH_KNN};
+    const int* full_order = nullptr;
+    if ((rc = get_full_order(c, &full_order))) return rc;
+    QuerySet q{&c->src, nullptr, c->src.n, 0, c->prm.color_icp != 0 && c->prm.matching == ICP_MATCH_KNN, false, full_order};
     if ((rc = launch_match(c, q))) return rc;
     if ((rc = ensure(c, c->sums, NSUM * 8))) return rc;
     if ((rc = launch_post_and_solve(c, nullptr, q.n, nullptr, c->sums.as<double>(), 0, nullptr))) return rc;
@@ -544,14 +606,21 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     if ((rc = ensure_events(c, (size_t)iters * 3 + 1))) return rc;
     // resolve selections up front (uploads) so the loop itself is launch-only
     std::vector<const int*> sels(iters, nullptr); std::vector<int> ns(iters, c->src.n);
-    for (int i = 0; i < iters; i++) if (factors[i] > 0) { if ((rc = get_level(c, factors[i], &sels[i], &ns[i]))) return rc; }
+    std::vector<const int*> orders(iters, nullptr);
+    const bool want_order = p.matching == ICP_MATCH_KNN && p.knn_backend == ICP_KNN_LBVH && !p.color_icp;
+    for (int i = 0; i < iters; i++) {
+        if (factors[i] > 0) { if ((rc = get_level(c, factors[i], &sels[i], &ns[i], want_order ? &orders[i] : nullptr))) return rc; }
+        else if (want_order) { if ((rc = get_full_order(c, &orders[i]))) return rc; }
+    }
     const bool rmse = p.record_rmse && c->conv_n > 0;
     if (rmse) { if ((rc = ensure(c, c->rmse_partials, 256 * 2 * 8))) return rc; }
     HIPCK(c, hipEventRecord(c->events[0], c->stream));
     for (int i = 0; i < iters; i++) {
         icp_iter_stats* d_st = c->stats.as<icp_iter_stats>() + i;
         if (ns[i] > 0) {
-            QuerySet q{&c->src, sels[i], ns[i], 0, p.color_icp != 0 && p.matching == ICP_MATCH_KNN};
+            // seed the search with the previous iteration's neighbours when it matched the same queries (same level)
+            const bool seed = i > 0 && factors[i] == factors[i - 1] && ns[i - 1] > 0;
+            QuerySet q{&c->src, sels[i], ns[i], 0, p.color_icp != 0 && p.matching == ICP_MATCH_KNN, seed, orders[i]};
             if ((rc = launch_match(c, q))) return rc;
             HIPCK(c, hipEventRecord(c->events[1 + 3 * i], c->stream));
             if ((rc = launch_post_and_solve(c, sels[i], ns[i], d_st, nullptr, 1, c->events[2 + 3 * i]))) return rc;

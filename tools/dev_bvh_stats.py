@@ -6,12 +6,9 @@ from icp_amd import binding, synth
 binding.LIB_PATH = os.path.join(binding.PKG_ROOT, "lib", "libicp_hip_stats.so")
 p = synth.eth_like_pair(0)
 c = binding.Context(0)
-c.params.max_distance = 10.0; c.params.knn_backend = 1; c.push_params()
+c.params.max_distance = 1e30; c.params.knn_backend = 1; c.push_params()
 c.set_target(p["tgt_pts"], p["tgt_nrm"]); c.set_source(p["src_pts"], p["src_nrm"])
 for name, T in (("identity", np.eye(4)), ("gt", p["gt"])):
     m, st = c.match(T)
     st = st.astype(np.int64); nodes = st % 4096; leaves = st // 4096
-    print(name, "nodes mean/med/p99/max", nodes.mean(), np.median(nodes), np.percentile(nodes, 99), nodes.max(), "leaves mean/med/p99/max", leaves.mean(), np.median(leaves), np.percentile(leaves, 99), leaves.max())
-    # per-wave max (divergence cost)
-    w = nodes[: len(nodes) // 64 * 64].reshape(-1, 64); wl = leaves[: len(leaves) // 64 * 64].reshape(-1, 64)
-    print("   per-wave max nodes mean", w.max(1).mean(), "leaves", wl.max(1).mean())
+    print(name, "PACKET per-wave nodes mean/med/p99/max", nodes.mean(), np.median(nodes), np.percentile(nodes, 99), nodes.max(), "leaves", leaves.mean(), np.median(leaves), np.percentile(leaves, 99), leaves.max())
