@@ -251,35 +251,49 @@ __device__ __forceinline__ float from_ordered_bits(unsigned int u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
 }
 
-// compaction of the finite targets: perm[0..n_valid) = their indices in increasing order (host supplies it)
-// Per-level bounding boxes of the nodes (ordered-uint atomics; a wave that lies inside one node reduces first).
-__global__ void k_bvh_level_boxes(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                                  const int* __restrict__ perm, int n_valid, int seg_shift, unsigned int* __restrict__ boxes /* [nodes][6] */) {
+// Per-level bounding boxes of the nodes, without contended atomics:
+//   k_bvh_wave_boxes : every wave (or aligned sub-wave segment of 32 / 16 positions, for the last levels) reduces the box
+//                      of its consecutive positions with a shuffle tree -> segbox[segment][6]
+//   k_bvh_node_boxes : one wave per node folds the node's wave boxes (segments of >= 64 positions are wave-aligned)
+__global__ void k_bvh_wave_boxes(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                 const int* __restrict__ perm, int n_valid, int seg_shift /* <= 6 */, unsigned int* __restrict__ segbox) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool act = i < n_valid;
     const int j = act ? perm[i] : 0;
     unsigned int v[6];
     if (act) { const unsigned int a = ordered_bits(x[j]), b = ordered_bits(y[j]), c = ordered_bits(z[j]); v[0] = a; v[1] = b; v[2] = c; v[3] = a; v[4] = b; v[5] = c; }
     else { v[0] = v[1] = v[2] = 0xFFFFFFFFu; v[3] = v[4] = v[5] = 0u; }
-    const int node = i >> seg_shift;
-    if (seg_shift >= 6) {            // segment size >= 64 and wave-aligned: the whole wave is in one node
+    const int seg = 1 << seg_shift;                       // 64 (whole wave) or a sub-wave segment of 32 / 16 positions
+    for (int off = seg >> 1; off > 0; off >>= 1) {
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
+        for (int k = 0; k < 3; k++) { v[k] = min(v[k], (unsigned int)__shfl_down((int)v[k], off, 64)); v[3 + k] = max(v[3 + k], (unsigned int)__shfl_down((int)v[3 + k], off, 64)); }
+    }
+    // (a lane's partial result may have mixed in lanes of the NEXT segment only for lanes that are not segment heads)
+    if ((threadIdx.x & (seg - 1)) == 0 && (i < n_valid || seg == 64)) {
+        unsigned int* o = segbox + (size_t)(i >> seg_shift) * 6;
 #pragma unroll
-            for (int k = 0; k < 3; k++) { v[k] = min(v[k], (unsigned int)__shfl_down((int)v[k], off, 64)); v[3 + k] = max(v[3 + k], (unsigned int)__shfl_down((int)v[3 + k], off, 64)); }
-        }
-        if ((threadIdx.x & 63) == 0 && (i < n_valid)) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) { atomicMin(boxes + (size_t)node * 6 + k, v[k]); atomicMax(boxes + (size_t)node * 6 + 3 + k, v[3 + k]); }
-        }
-    } else if (act) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) { atomicMin(boxes + (size_t)node * 6 + k, v[k]); atomicMax(boxes + (size_t)node * 6 + 3 + k, v[3 + k]); }
+        for (int k = 0; k < 6; k++) o[k] = v[k];
     }
 }
-__global__ void k_bvh_reset_boxes(unsigned int* boxes, int n_nodes) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_nodes * 6) boxes[t] = ((t % 6) < 3) ? 0xFFFFFFFFu : 0u;
+__global__ void k_bvh_node_boxes(const unsigned int* __restrict__ wavebox, int n_waves, int waves_per_node_shift, int n_nodes, unsigned int* __restrict__ boxes) {
+    const int node = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (node >= n_nodes) return;
+    const int w0 = node << waves_per_node_shift, w1 = min(w0 + (1 << waves_per_node_shift), n_waves);
+    unsigned int v[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    for (int w = w0 + lane; w < w1; w += 64) {
+        const unsigned int* b = wavebox + (size_t)w * 6;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { v[k] = min(v[k], b[k]); v[3 + k] = max(v[3 + k], b[3 + k]); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { v[k] = min(v[k], (unsigned int)__shfl_down((int)v[k], off, 64)); v[3 + k] = max(v[3 + k], (unsigned int)__shfl_down((int)v[3 + k], off, 64)); }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) boxes[(size_t)node * 6 + k] = v[k];
+    }
 }
 // sort key of every point at this level: (node id, coordinate along the node's widest axis)
 __global__ void k_bvh_level_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
@@ -358,9 +372,6 @@ __device__ __forceinline__ f2 pair_lb(const f2 lox, const f2 loy, const f2 loz, 
 }
 
 // Evaluate the 8 points of a leaf against the lane's query; exact lexicographic (d2, lowest index) update.
-// `wave_uniform_leaf`: the leaf pointer is wave-uniform (packet traversal) -> its 128 B arrive through scalar loads and
-// the update pass is skipped for the whole wave unless some lane ties or improves.
-template <bool wave_uniform_leaf>
 __device__ __forceinline__ void leaf_eval(const BvhLeaf* __restrict__ lf, const f2 px2, const f2 py2, const f2 pz2, float& best, int& bi) {
     float dd[BVH_LEAF];
     float m = FLT_MAX;
@@ -373,7 +384,7 @@ __device__ __forceinline__ void leaf_eval(const BvhLeaf* __restrict__ lf, const 
         m = fminf(fminf(m, d.x), d.y);
     }
     const bool hit = m <= best;          // something in this leaf ties or beats the running best
-    if (wave_uniform_leaf ? (__ballot(hit) != 0ull) : hit) {
+    if (hit) {
 #pragma unroll
         for (int t = 0; t < BVH_LEAF; t++) {
             const int j = lf->idx[t];
@@ -421,13 +432,12 @@ __device__ __forceinline__ void trav_pop(TravState& st, const unsigned short* __
     }
 }
 
-// Runs the "near child first" traversal until it finishes or `budget` node/leaf visits are spent.
-// "while-while" shape: busy lanes first descend through internal nodes, then evaluate their leaves together.
+// "Near child first" traversal to completion, "while-while" shape: busy lanes first descend through internal nodes,
+// then evaluate their leaves together.
 __device__ __forceinline__ void trav_run(const BvhView& bv, int tree_depth, const f2 px2, const f2 py2, const f2 pz2, TravState& st,
-                                         float& best, int& bi, unsigned short* __restrict__ lb16, int tid, int nthreads, int budget) {
-    int steps = 0;
-    while (st.alive && steps < budget) {
-        while (st.alive && st.depth < tree_depth && steps < budget) {
+                                         float& best, int& bi, unsigned short* __restrict__ lb16, int tid, int nthreads) {
+    while (st.alive) {
+        while (st.alive && st.depth < tree_depth) {
             const BvhNode* __restrict__ nd = bv.nodes + ((1 << st.depth) - 1 + st.idx);
             const f2 l = pair_lb(*(const f2*)nd->lox, *(const f2*)nd->loy, *(const f2*)nd->loz, *(const f2*)nd->hix, *(const f2*)nd->hiy, *(const f2*)nd->hiz, px2, py2, pz2);
             const bool swap = l.y < l.x;                  // child 1 is nearer
@@ -438,28 +448,22 @@ __device__ __forceinline__ void trav_run(const BvhView& bv, int tree_depth, cons
                 st.idx = 2 * st.idx + (swap ? 1 : 0); st.depth++;
             } else st.alive = false;                      // both children pruned (lf >= ln)
             trav_pop(st, lb16, tid, nthreads, best);
-            steps++;
         }
-        if (st.alive && st.depth == tree_depth && steps < budget) {
-            leaf_eval<false>(bv.leaves + st.idx, px2, py2, pz2, best, bi);
+        if (st.alive) {
+            leaf_eval(bv.leaves + st.idx, px2, py2, pz2, best, bi);
             st.alive = false;
             trav_pop(st, lb16, tid, nthreads, best);
-            steps++;
         }
     }
 }
 
-// Phase 1: every lane walks the tree on its own for its own query.  The kernel is bound by dependent-load latency (one
-// 64-B node record per step), so what moves it is occupancy, L2 locality (Morton-sorted queries, XCD-contiguous slices)
-// and -- above all -- the TAIL: a query whose neighbour is far away (non-overlapping part of the scans) has to open every
-// leaf that intersects its large search ball, hundreds of serial steps for one lane while the rest of the chip idles.
-// Such a query stops after BVH_BUDGET visits, parks its running best as a seed and is queued for k_knn_heavy, where a
-// whole wave finishes it cooperatively.
-constexpr int BVH_BUDGET = 96;
-
-struct HeavyQueue { int* list; int* count; int capacity; };
-
-__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, const BvhView bv, const int* __restrict__ qorder, int tree_depth, const HeavyQueue hq) {
+// Every lane walks the tree on its own for its own query.  Measured on MI355X (370k x 370k): ~26 node records and ~3 leaves
+// per query, 67 % of the wave time waiting on dependent loads, 33 % of the lanes active on average (traversal lengths
+// differ per lane).  What moved it: Morton-sorted queries + XCD-contiguous slices (L2 locality), the 2-byte-per-level
+// stack (occupancy), temporal seeding.  Tried and rejected (slower, see git history): wave-packet traversal with scalar
+// node loads (the union of 64 lanes' subtrees is 3x larger), persistent lanes with wave-level refill (fewer waves in
+// flight), a second cooperative pass for queries over a step budget.
+__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, const BvhView bv, const int* __restrict__ qorder, int tree_depth) {
     extern __shared__ unsigned short bvh_lb16[];          // [tree_depth + 1][BVH_THREADS]
     const int tid = threadIdx.x;
     const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS + tid;
@@ -473,16 +477,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, con
         seed_from_previous(kp, k, px, py, pz, best, bi);
         const f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz};
         TravState st; st.depth = 0; st.idx = 0; st.pending = 0u; st.alive = true;
-        trav_run(bv, tree_depth, px2, py2, pz2, st, best, bi, bvh_lb16, tid, BVH_THREADS, hq.list ? BVH_BUDGET : 0x7fffffff);
-        if (st.alive) {                                   // over budget: park (best, bi) as the seed and hand over to k_knn_heavy
-            const int slot = atomicAdd(hq.count, 1);
-            if (slot < hq.capacity) {
-                hq.list[slot] = k;
-                kp.nn_raw[k] = bi; kp.d2_out[k] = best;
-                return;
-            }
-            trav_run(bv, tree_depth, px2, py2, pz2, st, best, bi, bvh_lb16, tid, BVH_THREADS, 0x7fffffff);     // queue full: finish here
-        }
+        trav_run(bv, tree_depth, px2, py2, pz2, st, best, bi, bvh_lb16, tid, BVH_THREADS);
     }
     if (kp.nn_raw) kp.nn_raw[k] = bi;
     icp_match_t m;
@@ -491,128 +486,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, con
     if (kp.d2_out) kp.d2_out[k] = best;
 }
 
-// Phase 2: one WAVE per parked query.  The 64 lanes start at the 64 subtrees of depth 6 (fewer in a small tree), walk
-// them independently in short bursts and share the running best after every burst (lexicographic (d2, index) wave
-// minimum), so every lane prunes against the best candidate any lane has found.  The union of the subtrees is the whole
-// tree and every bound used for pruning is the distance of a real candidate => the result is the exact argmin.
-constexpr int HEAVY_WAVES = 4;
-__global__ __launch_bounds__(HEAVY_WAVES * WAVE) void k_knn_heavy(const KnnParams kp, const BvhView bv, int tree_depth, const HeavyQueue hq) {
-    extern __shared__ unsigned short bvh_lb16[];          // [tree_depth + 1][HEAVY_WAVES * WAVE]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int gw = blockIdx.x * HEAVY_WAVES + (tid >> 6), nw = gridDim.x * HEAVY_WAVES;
-    const int count = min(*hq.count, hq.capacity);
-    const int S = min(6, tree_depth);
-    for (int h = gw; h < count; h += nw) {
-        const int k = hq.list[h];
-        const int i = kp.sel ? kp.sel[k] : k;
-        float px = kp.sx[i], py = kp.sy[i], pz = kp.sz[i];
-        if (!kp.pretransformed) { float a, b, c; xform_point(kp.ps->pose, px, py, pz, a, b, c); px = a; py = b; pz = c; }
-        const f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz};
-        float best = kp.d2_out[k]; int bi = kp.nn_raw[k];     // seed parked by phase 1
-        TravState st; st.depth = S; st.idx = lane; st.pending = 0u; st.alive = lane < (1 << S);
-        if (st.alive && S > 0) {                              // bound of the lane's own subtree from its parent's record
-            const BvhNode* __restrict__ nd = bv.nodes + ((1 << (S - 1)) - 1 + (lane >> 1));
-            const f2 l = pair_lb(*(const f2*)nd->lox, *(const f2*)nd->loy, *(const f2*)nd->loz, *(const f2*)nd->hix, *(const f2*)nd->hiy, *(const f2*)nd->hiz, px2, py2, pz2);
-            const float lb = (lane & 1) ? l.y : l.x;
-            st.alive = !(lb * 0.99999f > best);
-        }
-        while (__ballot(st.alive) != 0ull) {
-            trav_run(bv, tree_depth, px2, py2, pz2, st, best, bi, bvh_lb16, tid, HEAVY_WAVES * WAVE, 8);
-            // share the best candidate: lexicographic (d2, index) minimum over the wave
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const float od = __shfl_xor(best, off, WAVE); const int oi = __shfl_xor(bi, off, WAVE);
-                const bool take = (od < best) | ((od == best) & (oi < bi) & (oi >= 0)) | ((od == best) & (bi < 0) & (oi >= 0));
-                best = take ? od : best; bi = take ? oi : bi;
-            }
-            if (!st.alive) trav_pop(st, bvh_lb16, tid, HEAVY_WAVES * WAVE, best);     // (no-op: pop already ran; keeps the state consistent)
-        }
-        if (lane == 0) {
-            kp.nn_raw[k] = bi;
-            icp_match_t m;
-            if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
-            kp.out[k] = m;
-            kp.d2_out[k] = best;
-        }
-    }
-}
-
-// Packet traversal: the 64 lanes of a wave are 64 spatially adjacent queries (qorder = Morton order of the source) and
-// walk the tree TOGETHER.  The current node is wave-uniform, so node records and leaves arrive through scalar loads
-// (SGPR operands of the packed-f32 math), the node stack is one scalar stack per wave and all control flow is scalar --
-// no exec-mask divergence and no per-lane stack traffic except one lower-bound word per push.  A subtree is entered if ANY lane
-// still needs it; every lane evaluates every leaf the packet opens (extra candidates never hurt exactness) and keeps
-// its own running best, so each lane's result is the exact lexicographic minimum.
-constexpr int PK_WAVES = 4;
-__global__ __launch_bounds__(PK_WAVES * WAVE) void k_knn_packet(const KnnParams kp, const BvhView bv, const int* __restrict__ qorder) {
-    __shared__ float st_lb[PK_WAVES][BVH_MAXD][WAVE];
-    __shared__ int st_node[PK_WAVES][BVH_MAXD];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = (blockIdx.x * PK_WAVES + w) * WAVE + lane;
-    const bool act = t < kp.n;
-    const int k = act ? (qorder ? qorder[t] : t) : 0;
-    const int i = kp.sel ? kp.sel[k] : k;
-    float px = kp.sx[i], py = kp.sy[i], pz = kp.sz[i];
-    if (!kp.pretransformed) { float a, b, c; xform_point(kp.ps->pose, px, py, pz, a, b, c); px = a; py = b; pz = c; }
-    const bool live = act && finite3(px, py, pz) && bv.n_valid > 0;
-    float best = FLT_MAX; int bi = -1;
-    if (live) seed_from_previous(kp, k, px, py, pz, best, bi);
-    if (!live) best = -1.f;                              // never needs a node, never takes a candidate
-    if (__ballot(live) != 0ull) {
-        const f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz};
-        const int first_leaf = bv.Lp - 1;
-        int sp = 0, node = 0;                            // wave-uniform
-#ifdef ICP_BVH_STATS
-        int n_nodes_v = 0, n_leaves_v = 0;
-#endif
-        while (node >= 0) {
-            node = __builtin_amdgcn_readfirstlane(node);  // (already uniform: tells the compiler so -> scalar loads, scalar branches)
-#ifdef ICP_BVH_STATS
-            if (node >= first_leaf) n_leaves_v++; else n_nodes_v++;
-#endif
-            if (node >= first_leaf) {
-                leaf_eval<true>(bv.leaves + (node - first_leaf), px2, py2, pz2, best, bi);
-                node = -1;
-            } else {
-                const BvhNode* __restrict__ nd = bv.nodes + node;     // uniform address -> s_load_dwordx16
-                const f2 l = pair_lb(*(const f2*)nd->lox, *(const f2*)nd->loy, *(const f2*)nd->loz, *(const f2*)nd->hix, *(const f2*)nd->hiy, *(const f2*)nd->hiz, px2, py2, pz2);
-                const bool need0 = !(l.x * 0.99999f > best), need1 = !(l.y * 0.99999f > best);
-                const unsigned long long b0 = __ballot(need0), b1 = __ballot(need1);
-                const int c0 = 2 * node + 1;
-                if ((b0 | b1) == 0ull) node = -1;
-                else if (b1 == 0ull) node = c0;
-                else if (b0 == 0ull) node = c0 + 1;
-                else {
-                    // both subtrees are needed by someone: descend into the one most lanes are closer to, keep the other
-                    const unsigned long long p1 = __ballot((need0 | need1) & (l.y < l.x));
-                    const int n1 = __popcll(p1), nall = __popcll(b0 | b1);
-                    const bool first1 = 2 * n1 > nall;
-                    st_lb[w][sp][lane] = first1 ? l.x : l.y;
-                    if (lane == 0) st_node[w][sp] = first1 ? c0 : c0 + 1;
-                    sp++;
-                    node = first1 ? c0 + 1 : c0;
-                }
-            }
-            while (node < 0 && sp > 0) {                 // pop until some lane still needs the entry
-                --sp;
-                if (__ballot(!(st_lb[w][sp][lane] * 0.99999f > best)) != 0ull) node = __builtin_amdgcn_readfirstlane(st_node[w][sp]);
-            }
-        }
-#ifdef ICP_BVH_STATS
-        if (live) best = (float)(n_nodes_v + 4096 * n_leaves_v);
-#endif
-    }
-    if (!act) return;
-    if (!live) { best = FLT_MAX; bi = -1; }
-    if (kp.nn_raw) kp.nn_raw[k] = bi;
-    icp_match_t m;
-    if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
-    kp.out[k] = m;
-    if (kp.d2_out) kp.d2_out[k] = best;
-}
-
-// Morton key of the (untransformed) query points -> spatially coherent wave packets for k_knn_packet.
+// Morton key of the (untransformed) query points -> spatially coherent waves for k_knn_bvh.
 __global__ void k_query_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const int* __restrict__ sel, int n,
                              float lox, float loy, float loz, float sx, float sy, float sz, unsigned long long* __restrict__ keys, int* __restrict__ vals) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;

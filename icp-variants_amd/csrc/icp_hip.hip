@@ -48,7 +48,7 @@ struct Level { DevBuf idx; DevBuf order; int n = 0; };   // selection (original 
 struct Bvh {
     bool valid = false;
     int n_valid = 0, n_leaves = 0, Lp = 1;
-    DevBuf keys, keys2, vals, vals2, temp, leaves, nodes, lvl;
+    DevBuf keys, keys2, vals, vals2, temp, leaves, nodes, lvl, wbox;
     std::vector<int> finite_idx;                     // indices of the finite target points, increasing
     double build_ms = 0.0;
 };
@@ -66,7 +66,7 @@ struct icp_ctx {
     float src_lo[3] = {0, 0, 0}, src_hi[3] = {0, 0, 0};   // bounding box of the finite source points
     DevBuf order_full, okeys, okeys2, ovals, otemp; bool order_full_valid = false;   // Morton order of the full source
     std::map<int, Level> levels;         // multires selections by decimation factor
-    DevBuf ps, matches, d2, best64, nn_raw, heavy, partials, sums, stats, staging, rmse_partials, rmse_out;
+    DevBuf ps, matches, d2, best64, nn_raw, partials, sums, stats, staging, rmse_partials, rmse_out;
     Cloud conv_src, conv_ref; int conv_n = 0;
     float cos_reject = 0.5f;
     std::vector<hipEvent_t> events;
@@ -217,6 +217,7 @@ int build_bvh(icp_ctx* c) {
     if ((rc = ensure(c, b.leaves, (size_t)(n_slots / BVH_LEAF) * sizeof(BvhLeaf)))) return rc;
     if ((rc = ensure(c, b.nodes, (size_t)(n_inner > 0 ? n_inner : 1) * sizeof(BvhNode)))) return rc;
     if ((rc = ensure(c, b.lvl, (size_t)(b.Lp > 1 ? b.Lp / 2 : 1) * 6 * 4))) return rc;
+    if ((rc = ensure(c, b.wbox, (size_t)((cap + 63) / 64) * 6 * 4))) return rc;
     const float* tx = c->tgt.x.as<float>(); const float* ty = c->tgt.y.as<float>(); const float* tz = c->tgt.z.as<float>();
     int* perm = b.vals.as<int>(); int* perm2 = b.vals2.as<int>();
     if (nv > 0) {
@@ -230,8 +231,14 @@ int build_bvh(icp_ctx* c) {
             // segment (node) size at level d in points: BVH_LEAF * Lp / 2^d  = 1 << seg_shift
             int seg_shift = 0; { long long seg = (long long)BVH_LEAF * b.Lp >> d; while ((1LL << seg_shift) < seg) seg_shift++; }
             const int n_nodes = 1 << d;
-            hipLaunchKernelGGL(k_bvh_reset_boxes, dim3((n_nodes * 6 + 255) / 256), dim3(256), 0, c->stream, b.lvl.as<unsigned int>(), n_nodes);
-            hipLaunchKernelGGL(k_bvh_level_boxes, dim3(gb), dim3(256), 0, c->stream, tx, ty, tz, perm, nv, seg_shift, b.lvl.as<unsigned int>());
+            if (seg_shift >= 6) {            // wave-aligned segments: per-wave boxes, then one wave per node folds them
+                const int n_waves = (nv + 63) / 64;
+                hipLaunchKernelGGL(k_bvh_wave_boxes, dim3(gb), dim3(256), 0, c->stream, tx, ty, tz, perm, nv, 6, b.wbox.as<unsigned int>());
+                hipLaunchKernelGGL(k_bvh_node_boxes, dim3((n_nodes * 64 + 255) / 256), dim3(256), 0, c->stream, b.wbox.as<unsigned int>(), n_waves, seg_shift - 6, n_nodes,
+                                   b.lvl.as<unsigned int>());
+            } else {                         // sub-wave segments (last levels): the segment heads write the node boxes directly
+                hipLaunchKernelGGL(k_bvh_wave_boxes, dim3(gb), dim3(256), 0, c->stream, tx, ty, tz, perm, nv, seg_shift, b.lvl.as<unsigned int>());
+            }
             hipLaunchKernelGGL(k_bvh_level_keys, dim3(gb), dim3(256), 0, c->stream, tx, ty, tz, perm, nv, seg_shift, b.lvl.as<unsigned int>(), b.keys.as<unsigned long long>());
             HIPCK(c, rocprim::radix_sort_pairs(b.temp.p, temp_bytes, b.keys.as<unsigned long long>(), b.keys2.as<unsigned long long>(), perm, perm2, (size_t)nv, 0, 32 + d, c->stream));
             int* t = perm; perm = perm2; perm2 = t;
@@ -283,20 +290,10 @@ int launch_match(icp_ctx* c, const QuerySet& q) {
         kp.nseg = 1;
         if ((rc = ensure(c, c->nn_raw, (size_t)q.n * 4))) return rc;
         kp.nn_raw = c->nn_raw.as<int>(); kp.use_prev = q.seed_prev ? 1 : 0;
-        static const int use_packet = getenv("ICP_HIP_PACKET") ? atoi(getenv("ICP_HIP_PACKET")) : 0;
-        if (q.order && use_packet)
-            hipLaunchKernelGGL(k_knn_packet, dim3((q.n + PK_WAVES * WAVE - 1) / (PK_WAVES * WAVE)), dim3(PK_WAVES * WAVE), 0, c->stream, kp, bv, q.order);
-        else
         {
             int depth = 0; while ((1 << depth) < c->bvh.Lp) depth++;              // internal levels 0 .. depth-1, leaves at depth
-            const int cap = q.n < 65536 ? q.n : 65536;
-            if ((rc = ensure(c, c->heavy, (size_t)(cap + 64) * 4))) return rc;
-            HeavyQueue hq; hq.count = c->heavy.as<int>(); hq.list = hq.count + 64; hq.capacity = cap;
-            HIPCK(c, hipMemsetAsync(hq.count, 0, 4, c->stream));
             hipLaunchKernelGGL(k_knn_bvh, dim3((q.n + BVH_THREADS - 1) / BVH_THREADS), dim3(BVH_THREADS), (size_t)(depth + 1) * BVH_THREADS * 2, c->stream,
-                               kp, bv, q.order, depth, hq);
-            int hb = (cap + HEAVY_WAVES - 1) / HEAVY_WAVES; if (hb > 512) hb = 512;
-            hipLaunchKernelGGL(k_knn_heavy, dim3(hb), dim3(HEAVY_WAVES * WAVE), (size_t)(depth + 1) * HEAVY_WAVES * WAVE * 2, c->stream, kp, bv, depth, hq);
+                               kp, bv, q.order, depth);
         }
         HIPCK(c, hipGetLastError());
         return ICP_OK;
@@ -448,9 +445,9 @@ int icp_ctx_destroy(icp_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release(c->tgt); release(c->src); release(c->qry); release(c->conv_src); release(c->conv_ref);
-    release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->order_full); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl);
+    release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->order_full); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) { release(kv.second.idx); release(kv.second.order); }
-    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->heavy); release(c->partials); release(c->sums);
+    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->partials); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
