@@ -1093,6 +1093,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
         sp.stats->n_valid = (int)n;
         for (int i = 0; i < 16; i++) sp.stats->pose[i] = ps->pose[i];
         sp.stats->rmse = -1.f;
+        sp.stats->benchmark_error = -1.f;
         sp.stats->status = status;
     }
 }
@@ -1123,6 +1124,105 @@ __global__ void k_rmse_finish(const double* __restrict__ partials, int nblocks, 
     double s = 0.0, c = 0.0;
     for (int b = 0; b < nblocks; b++) { s += partials[b * 2]; c += partials[b * 2 + 1]; }
     *out = (float)sqrt(s / c);
+}
+
+// ConvergenceMeasure::benchmarkError / calculate_error (ConvergenceMeasure.h:104-151), the Fontana-style metric of the ETH
+// runs:  mean_i ( |T s_i - r_i| / |T s_i - centroid(T s)| ).  Pass 1: fp64 sums of the transformed points (PCL's
+// compute3DCentroid accumulates in double), pass 2: fp32 distances as pcl::euclideanDistance computes them, fp64 sum.
+__global__ __launch_bounds__(256) void k_fontana_centroid(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+                                                          int n, const PoseState* __restrict__ ps, double* __restrict__ partials /* [blocks][4] */) {
+    __shared__ double lds[4 * 3];
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+        float a, b, c; xform_point(ps->pose, sx[k], sy[k], sz[k], a, b, c);
+        acc[0] += (double)a; acc[1] += (double)b; acc[2] += (double)c;
+    }
+    block_reduce<3>(acc, lds);
+    if (threadIdx.x == 0) { partials[blockIdx.x * 4] = acc[0]; partials[blockIdx.x * 4 + 1] = acc[1]; partials[blockIdx.x * 4 + 2] = acc[2]; }
+}
+__global__ __launch_bounds__(256) void k_fontana_error(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+                                                       const float* __restrict__ rx, const float* __restrict__ ry, const float* __restrict__ rz,
+                                                       int n, const PoseState* __restrict__ ps, const double* __restrict__ cpart, int cblocks,
+                                                       double* __restrict__ partials /* [blocks] */) {
+    __shared__ double lds[4];
+    __shared__ float cen[3];
+    if (threadIdx.x < 3) {        // every block folds the centroid partials in the same fixed order
+        double s = 0.0; for (int b = 0; b < cblocks; b++) s += cpart[b * 4 + threadIdx.x];
+        cen[threadIdx.x] = (float)(s / (double)n);                    // pcl::PointXYZ centroid(centroid_v[0], ...) :114
+    }
+    __syncthreads();
+    const float c0 = cen[0], c1 = cen[1], c2 = cen[2];
+    double acc[1] = {0.0};
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+        float a, b, c; xform_point(ps->pose, sx[k], sy[k], sz[k], a, b, c);
+        const float e0 = a - rx[k], e1 = b - ry[k], e2 = c - rz[k];
+        const float g0 = a - c0, g1 = b - c1, g2 = c - c2;
+        const float dist = sqrtf(e0 * e0 + (e1 * e1 + e2 * e2));      // euclideanDistance: (p1 - p2).norm() in fp32
+        const float cdist = sqrtf(g0 * g0 + (g1 * g1 + g2 * g2));
+        acc[0] += (double)dist / (double)cdist;                        // :117-119 (double division)
+    }
+    block_reduce<1>(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc[0];
+}
+__global__ void k_fontana_finish(const double* __restrict__ partials, int nblocks, int n, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; b++) s += partials[b];
+    *out = (float)(s / (double)n);
+}
+
+// RANDOM_SAMPLING selection (selection.h:88-106): every point of the current (possibly decimated) cloud is kept with
+// probability p, independently per iteration.  The reference draws from std::mt19937 seeded by random_device; here the
+// decision is a counter-based hash of (seed, iteration, original point index), identical on host and device, and the
+// kept points are compacted in increasing order (stable, deterministic): block counts -> scan -> scatter.
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
+__host__ __device__ __forceinline__ uint32_t select_hash(uint32_t seed, uint32_t iteration, uint32_t index) {
+    return fmix32(index * 0x9E3779B9u + fmix32(seed + iteration * 0x7F4A7C15u + 0x165667B1u));
+}
+__global__ __launch_bounds__(256) void k_select_count(const int* __restrict__ base, int n, uint32_t seed, uint32_t iteration, uint32_t threshold, int take_all,
+                                                      int* __restrict__ block_counts) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    if (t < n) { const int i = base ? base[t] : t; keep = take_all || select_hash(seed, iteration, (uint32_t)i) < threshold; }
+    const int c = __syncthreads_count(keep ? 1 : 0);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = c;
+}
+__global__ __launch_bounds__(1024) void k_select_scan(int* __restrict__ block_counts, int nblocks, int* __restrict__ total_out) {
+    __shared__ int carry;
+    __shared__ int tmp[1024];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nblocks; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        const int v = b < nblocks ? block_counts[b] : 0;
+        tmp[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {             // Hillis-Steele inclusive scan
+            const int a = threadIdx.x >= off ? tmp[threadIdx.x - off] : 0;
+            __syncthreads();
+            tmp[threadIdx.x] += a;
+            __syncthreads();
+        }
+        if (b < nblocks) block_counts[b] = carry + tmp[threadIdx.x] - v;     // exclusive offset of block b
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += tmp[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+__global__ __launch_bounds__(256) void k_select_scatter(const int* __restrict__ base, int n, uint32_t seed, uint32_t iteration, uint32_t threshold, int take_all,
+                                                        const int* __restrict__ block_offsets, int* __restrict__ out) {
+    __shared__ int wave_off[4];
+    const int t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int i = 0; bool keep = false;
+    if (t < n) { i = base ? base[t] : t; keep = take_all || select_hash(seed, iteration, (uint32_t)i) < threshold; }
+    const unsigned long long m = __ballot(keep);
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+    if (lane == 0) wave_off[w] = __popcll(m);
+    __syncthreads();
+    int off = block_offsets[blockIdx.x];
+    for (int v = 0; v < w; v++) off += wave_off[v];
+    if (keep) out[off + rank] = i;
 }
 
 // utils.h:106-133 as stand-alone kernels for the adaptor's transformPoints / transformNormals

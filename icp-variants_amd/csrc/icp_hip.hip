@@ -66,7 +66,8 @@ struct icp_ctx {
     float src_lo[3] = {0, 0, 0}, src_hi[3] = {0, 0, 0};   // bounding box of the finite source points
     DevBuf order_full, okeys, okeys2, ovals, otemp; bool order_full_valid = false;   // Morton order of the full source
     std::map<int, Level> levels;         // multires selections by decimation factor
-    DevBuf ps, matches, d2, best64, nn_raw, partials, sums, stats, staging, rmse_partials, rmse_out;
+    DevBuf sel_lists, sel_counts, sel_blocks;            // RANDOM_SAMPLING: per-iteration index lists, their sizes, scan scratch
+    DevBuf ps, matches, d2, best64, nn_raw, partials, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
     Cloud conv_src, conv_ref; int conv_n = 0;
     float cos_reject = 0.5f;
     std::vector<hipEvent_t> events;
@@ -414,12 +415,15 @@ extern "C" {
 
 const char* icp_version(void) { return "icp_hip gfx950 r1"; }
 
+uint32_t icp_select_hash(uint32_t seed, uint32_t iteration, uint32_t index) { return select_hash(seed, iteration, index); }
+
 int icp_params_default(icp_params* p) {
     if (!p) return ICP_ERR_INVALID_ARG;
     memset(p, 0, sizeof(*p));
     p->metric = 0; p->matching = 0; p->weighting = 0; p->rejection = 1; p->color_icp = 0; p->multires = 0;   // ICPOptimizer.h:29-31
     p->n_iterations = 20; p->max_distance = 0.0003f;
     p->knn_backend = ICP_KNN_BRUTE_FORCE; p->record_rmse = 0;
+    p->selection = 0; p->selection_proba = 1.0f; p->selection_seed = 0u;      // setSelectionMethod(SELECT_ALL), proba default 1.0 (ICPOptimizer.h:58)
     return ICP_OK;
 }
 
@@ -456,8 +460,8 @@ int icp_ctx_destroy(icp_ctx* c) {
     for (Bvh* b : {&c->bvh6}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
     release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->order_full); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) { release(kv.second.idx); release(kv.second.order); }
-    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->partials); release(c->sums);
-    release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out);
+    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->sums);
+    release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -468,7 +472,7 @@ const char* icp_last_error(const icp_ctx* c) { return c ? c->err.c_str() : "null
 
 int icp_set_params(icp_ctx* c, const icp_params* p) {
     if (!c || !p) return ICP_ERR_INVALID_ARG;
-    if (p->metric < 0 || p->metric > 2 || p->matching < 0 || p->matching > 1 || p->weighting < 0 || p->weighting > 3 || p->n_iterations < 0) {
+    if (p->metric < 0 || p->metric > 2 || p->matching < 0 || p->matching > 1 || p->weighting < 0 || p->weighting > 3 || p->n_iterations < 0 || p->selection < 0 || p->selection > 1) {
         c->err = "icp_set_params: value out of range"; return ICP_ERR_INVALID_ARG;
     }
     c->prm = *p;
@@ -595,6 +599,8 @@ int icp_schedule(const icp_params* p, int32_t n_src, int32_t* factors_out, int32
     return ICP_OK;
 }
 
+static int enqueue_fontana(icp_ctx* c, float* d_out);
+
 static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int32_t max_stats, int32_t* n_run, bool single) {
     const icp_params& p = c->prm;
     int rc;
@@ -623,14 +629,41 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
         if (factors[i] > 0) { if ((rc = get_level(c, factors[i], &sels[i], &ns[i], want_order ? &orders[i] : nullptr))) return rc; }
         else if (want_order) { if ((rc = get_full_order(c, &orders[i]))) return rc; }
     }
-    const bool rmse = p.record_rmse && c->conv_n > 0;
+    if (!single && p.selection == 1) {
+        // RANDOM_SAMPLING (ICPOptimizer.h:549-550: resample at the start of every iteration, over the current level's cloud).
+        // All resamples are drawn up front on the device; one small copy returns their sizes so the loop stays launch-only.
+        double th = (double)p.selection_proba * 4294967296.0;
+        const int take_all = th >= 4294967296.0 ? 1 : 0;
+        const uint32_t threshold = th <= 0.0 ? 0u : (take_all ? 0xFFFFFFFFu : (uint32_t)th);
+        const size_t cap = (size_t)c->src.n;
+        if ((rc = ensure(c, c->sel_lists, (size_t)iters * cap * 4))) return rc;
+        if ((rc = ensure(c, c->sel_counts, (size_t)iters * 4))) return rc;
+        if ((rc = ensure(c, c->sel_blocks, (size_t)((cap + 255) / 256 + 1) * 4))) return rc;
+        for (int i = 0; i < iters; i++) {
+            const int nb = (ns[i] + 255) / 256;
+            int* out = c->sel_lists.as<int>() + (size_t)i * cap;
+            if (ns[i] > 0) {
+                hipLaunchKernelGGL(k_select_count, dim3(nb), dim3(256), 0, c->stream, sels[i], ns[i], p.selection_seed, (uint32_t)i, threshold, take_all, c->sel_blocks.as<int>());
+                hipLaunchKernelGGL(k_select_scan, dim3(1), dim3(1024), 0, c->stream, c->sel_blocks.as<int>(), nb, c->sel_counts.as<int>() + i);
+                hipLaunchKernelGGL(k_select_scatter, dim3(nb), dim3(256), 0, c->stream, sels[i], ns[i], p.selection_seed, (uint32_t)i, threshold, take_all, c->sel_blocks.as<int>(), out);
+            } else HIPCK(c, hipMemsetAsync(c->sel_counts.as<int>() + i, 0, 4, c->stream));
+            sels[i] = out; orders[i] = nullptr;
+        }
+        HIPCK(c, hipGetLastError());
+        std::vector<int> counts((size_t)iters);
+        HIPCK(c, hipMemcpyAsync(counts.data(), c->sel_counts.p, (size_t)iters * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < iters; i++) ns[i] = counts[i];
+    }
+    const bool rmse = (p.record_rmse & 1) && c->conv_n > 0;
+    const bool fontana = (p.record_rmse & 2) && c->conv_n > 0;
     if (rmse) { if ((rc = ensure(c, c->rmse_partials, 256 * 2 * 8))) return rc; }
     HIPCK(c, hipEventRecord(c->events[0], c->stream));
     for (int i = 0; i < iters; i++) {
         icp_iter_stats* d_st = c->stats.as<icp_iter_stats>() + i;
         if (ns[i] > 0) {
             // seed the search with the previous iteration's neighbours when it matched the same queries (same level)
-            const bool seed = i > 0 && factors[i] == factors[i - 1] && ns[i - 1] > 0;
+            const bool seed = i > 0 && factors[i] == factors[i - 1] && ns[i - 1] > 0 && p.selection == 0;
             QuerySet q{&c->src, sels[i], ns[i], 0, p.color_icp != 0 && p.matching == ICP_MATCH_KNN, seed, orders[i]};
             if ((rc = launch_match(c, q))) return rc;
             HIPCK(c, hipEventRecord(c->events[1 + 3 * i], c->stream));
@@ -644,6 +677,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
                                c->conv_ref.x.as<float>(), c->conv_ref.y.as<float>(), c->conv_ref.z.as<float>(), c->conv_n, c->ps.as<PoseState>(), c->rmse_partials.as<double>());
             hipLaunchKernelGGL(k_rmse_finish, dim3(1), dim3(64), 0, c->stream, c->rmse_partials.as<double>(), 256, &d_st->rmse);
         }
+        if (fontana && (rc = enqueue_fontana(c, &d_st->benchmark_error))) return rc;
         HIPCK(c, hipEventRecord(c->events[3 + 3 * i], c->stream));
     }
     std::vector<icp_iter_stats> hs((size_t)iters);
@@ -654,8 +688,9 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     memcpy(pose_inout, hp.pose, 64);
     int status = ICP_OK;
     for (int i = 0; i < iters; i++) {
-        if (ns[i] <= 0) { hs[i].n_src = 0; hs[i].status = ICP_ERR_NO_CORRESPONDENCES; memcpy(hs[i].pose, i ? hs[i - 1].pose : pose_inout, 64); hs[i].rmse = -1.f; }
+        if (ns[i] <= 0) { hs[i].n_src = 0; hs[i].status = ICP_ERR_NO_CORRESPONDENCES; memcpy(hs[i].pose, i ? hs[i - 1].pose : pose_inout, 64); hs[i].rmse = -1.f; hs[i].benchmark_error = -1.f; }
         if (!rmse) hs[i].rmse = -1.f;
+        if (!fontana) hs[i].benchmark_error = -1.f;
         if (hs[i].status != ICP_OK && status == ICP_OK) status = hs[i].status;
         if (stats && i < max_stats) stats[i] = hs[i];
     }
@@ -693,6 +728,32 @@ int icp_set_convergence_reference(icp_ctx* c, const float* src_xyz, const float*
     if ((rc = upload3(c, src_xyz, n, n, 0.f, c->conv_src.x, c->conv_src.y, c->conv_src.z))) return rc;
     if ((rc = upload3(c, ref_xyz, n, n, 0.f, c->conv_ref.x, c->conv_ref.y, c->conv_ref.z))) return rc;
     c->conv_n = n;
+    return ICP_OK;
+}
+
+static int enqueue_fontana(icp_ctx* c, float* d_out) {
+    int rc;
+    if ((rc = ensure(c, c->fontana_partials, (size_t)256 * 5 * 8))) return rc;
+    double* cpart = c->fontana_partials.as<double>(); double* epart = cpart + 256 * 4;
+    hipLaunchKernelGGL(k_fontana_centroid, dim3(256), dim3(256), 0, c->stream, c->conv_src.x.as<float>(), c->conv_src.y.as<float>(), c->conv_src.z.as<float>(),
+                       c->conv_n, c->ps.as<PoseState>(), cpart);
+    hipLaunchKernelGGL(k_fontana_error, dim3(256), dim3(256), 0, c->stream, c->conv_src.x.as<float>(), c->conv_src.y.as<float>(), c->conv_src.z.as<float>(),
+                       c->conv_ref.x.as<float>(), c->conv_ref.y.as<float>(), c->conv_ref.z.as<float>(), c->conv_n, c->ps.as<PoseState>(), cpart, 256, epart);
+    hipLaunchKernelGGL(k_fontana_finish, dim3(1), dim3(64), 0, c->stream, epart, 256, c->conv_n, d_out);
+    HIPCK(c, hipGetLastError());
+    return ICP_OK;
+}
+
+int icp_benchmark_error(icp_ctx* c, const float pose[16], float* error_out) {
+    if (!c || !pose || !error_out) return ICP_ERR_INVALID_ARG;
+    if (c->conv_n <= 0) { c->err = "icp_benchmark_error: no convergence reference set"; return ICP_ERR_INVALID_ARG; }
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = write_pose(c, pose))) return rc;
+    if ((rc = ensure(c, c->rmse_out, 4))) return rc;
+    if ((rc = enqueue_fontana(c, c->rmse_out.as<float>()))) return rc;
+    HIPCK(c, hipMemcpyAsync(error_out, c->rmse_out.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
     return ICP_OK;
 }
 

@@ -32,11 +32,13 @@ class IcpParams(C.Structure):
     _fields_ = [("metric", C.c_int32), ("matching", C.c_int32), ("weighting", C.c_int32), ("rejection", C.c_int32),
                 ("color_icp", C.c_int32), ("multires", C.c_int32), ("n_iterations", C.c_int32), ("max_distance", C.c_float),
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
-                ("width", C.c_int32), ("height", C.c_int32), ("knn_backend", C.c_int32), ("record_rmse", C.c_int32)]
+                ("width", C.c_int32), ("height", C.c_int32), ("knn_backend", C.c_int32),
+                ("selection", C.c_int32), ("selection_proba", C.c_float), ("selection_seed", C.c_uint32), ("record_rmse", C.c_int32)]
 
 
 class IcpIterStats(C.Structure):
-    _fields_ = [("n_src", C.c_int32), ("n_valid", C.c_int32), ("pose", C.c_float * 16), ("rmse", C.c_float), ("status", C.c_int32)]
+    _fields_ = [("n_src", C.c_int32), ("n_valid", C.c_int32), ("pose", C.c_float * 16), ("rmse", C.c_float), ("benchmark_error", C.c_float),
+                ("status", C.c_int32)]
 
 
 class IcpTiming(C.Structure):
@@ -47,8 +49,8 @@ class IcpTiming(C.Structure):
 # every symbol include/icp_hip.h declares (tests check the library exports all of them)
 EXPORTS = ["icp_ctx_create", "icp_ctx_create_on_stream", "icp_ctx_destroy", "icp_last_error", "icp_params_default",
            "icp_set_params", "icp_get_params", "icp_set_target", "icp_set_source", "icp_query_matches", "icp_match",
-           "icp_correspond", "icp_iterate", "icp_run", "icp_get_timing", "icp_set_convergence_reference", "icp_rmse",
-           "icp_transform_points", "icp_transform_normals", "icp_version", "icp_schedule"]
+           "icp_correspond", "icp_iterate", "icp_run", "icp_get_timing", "icp_set_convergence_reference", "icp_rmse", "icp_benchmark_error",
+           "icp_transform_points", "icp_transform_normals", "icp_version", "icp_schedule", "icp_select_hash"]
 
 _lib = None
 
@@ -89,6 +91,11 @@ def schedule(params, n_src, max_out=4096):
     if rc != ICP_OK:
         raise IcpError(rc, "icp_schedule")
     return [buf[i] for i in range(min(cnt.value, max_out))]
+
+
+def select_hash(seed, iteration, index):
+    lib = load_library(); lib.icp_select_hash.restype = C.c_uint32
+    return int(lib.icp_select_hash(C.c_uint32(seed), C.c_uint32(iteration), C.c_uint32(index)))
 
 
 def default_params():
@@ -159,14 +166,14 @@ class Context:
     def iterate(self, pose):
         p = pose_to_c(pose); st = IcpIterStats()
         self._ck(self.lib.icp_iterate(self.h, _ptr(p), C.byref(st)))
-        return pose_from_c(p), dict(n_src=st.n_src, n_valid=st.n_valid, pose=pose_from_c(st.pose), rmse=st.rmse, status=st.status)
+        return pose_from_c(p), dict(n_src=st.n_src, n_valid=st.n_valid, pose=pose_from_c(st.pose), rmse=st.rmse, benchmark_error=st.benchmark_error, status=st.status)
 
     def run(self, pose, max_stats=512, check=True):
         p = pose_to_c(pose); st = (IcpIterStats * max_stats)(); n = C.c_int32(0)
         rc = self.lib.icp_run(self.h, _ptr(p), st, C.c_int32(max_stats), C.byref(n))
         if check:
             self._ck(rc)
-        recs = [dict(n_src=st[i].n_src, n_valid=st[i].n_valid, pose=pose_from_c(st[i].pose), rmse=st[i].rmse, status=st[i].status)
+        recs = [dict(n_src=st[i].n_src, n_valid=st[i].n_valid, pose=pose_from_c(st[i].pose), rmse=st[i].rmse, benchmark_error=st[i].benchmark_error, status=st[i].status)
                 for i in range(min(n.value, max_stats))]
         return pose_from_c(p), recs, rc
 
@@ -189,6 +196,11 @@ class Context:
     def rmse(self, pose):
         out = C.c_float(0)
         self._ck(self.lib.icp_rmse(self.h, _ptr(pose_to_c(pose)), C.byref(out)))
+        return out.value
+
+    def benchmark_error(self, pose):
+        out = C.c_float(0)
+        self._ck(self.lib.icp_benchmark_error(self.h, _ptr(pose_to_c(pose)), C.byref(out)))
         return out.value
 
     def transform_points(self, xyz, pose):
@@ -219,18 +231,17 @@ class LinearICPOptimizer:
     def setNbOfIterations(self, n): self.ctx.params.n_iterations = n                           # :84-86
     def setKnnBackend(self, b): self.ctx.params.knn_backend = b
 
-    def setSelectionMethod(self, method, proba=1.0):                                           # :58-61
-        if method != 0:
-            raise NotImplementedError("RANDOM_SAMPLING is seeded from random_device in the reference (selection.h:76-79); not on the parity path")
+    def setSelectionMethod(self, method, proba=1.0, seed=0):                                   # :58-61 (+ explicit seed)
+        self.ctx.params.selection = int(method); self.ctx.params.selection_proba = float(proba); self.ctx.params.selection_seed = int(seed)
 
     def setCameraParamsMatchingMethod(self, K, width, height):                                 # :80-82
         K = np.asarray(K, dtype=np.float32)
         p = self.ctx.params
         p.fx, p.fy, p.cx, p.cy, p.width, p.height = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), int(width), int(height)
 
-    def setConvergenceMeasure(self, src_xyz, ref_xyz):                                         # :93-95
+    def setConvergenceMeasure(self, src_xyz, ref_xyz, runBenchmark=False):                     # :93-95, ConvergenceMeasure.h:35-44
         self.ctx.set_convergence_reference(src_xyz, ref_xyz)
-        self.ctx.params.record_rmse = 1
+        self.ctx.params.record_rmse = 3 if runBenchmark else 1
 
     def estimatePose(self, source, target, initialPose, check=True):
         """source/target: dicts with 'pts', 'nrm', optional 'rgba'.  Returns (pose, per-iteration records)."""

@@ -64,7 +64,12 @@ typedef struct icp_params {
     float   fx, fy, cx, cy;  /* setCameraParamsMatchingMethod (ICPOptimizer.h:80-82) */
     int32_t width, height;
     int32_t knn_backend;     /* ICP_KNN_* (extension; the reference's own index is an approximate, randomised FLANN kd-tree) */
-    int32_t record_rmse;     /* 1: per-iteration RMSE against the convergence reference (ConvergenceMeasure.h:50-66) */
+    int32_t selection;       /* setSelectionMethod: 0 SELECT_ALL, 1 RANDOM_SAMPLING (selection.h:9)                          */
+    float   selection_proba; /* Bernoulli probability per point and per iteration (selection.h:88-106)                     */
+    uint32_t selection_seed; /* the reference seeds std::mt19937 from random_device (selection.h:76-79: not reproducible);
+                                here a counter-based hash of (seed, iteration, point index) decides -- see icp_select_hash */
+    int32_t record_rmse;     /* bit 0: per-iteration RMSE against the convergence reference (ConvergenceMeasure.h:50-66);
+                                bit 1: also the benchmark error (m_runBenchmark, ConvergenceMeasure.h:74-78,104-151) */
 } icp_params;
 
 /* Per-iteration record (what the reference prints / records each iteration, ICPOptimizer.h:541-631). */
@@ -73,6 +78,7 @@ typedef struct icp_iter_stats {
     int32_t n_valid;         /* correspondences that entered the solve (ICPOptimizer.h:594-610) */
     float   pose[16];        /* estimatedPose after the iteration, column-major */
     float   rmse;            /* RMSE vs convergence reference, or -1 */
+    float   benchmark_error; /* Fontana-style benchmark error (ConvergenceMeasure.h:104-151) when record_rmse & 2, or -1 */
     int32_t status;          /* ICP_OK or ICP_ERR_NO_CORRESPONDENCES for this iteration */
 } icp_iter_stats;
 
@@ -135,10 +141,16 @@ int icp_schedule(const icp_params* p, int32_t n_src, int32_t* factors_out, int32
  * src_xyz[i] (moved by the estimated pose) is compared with ref_xyz[i]. */
 int icp_set_convergence_reference(icp_ctx* ctx, const float* src_xyz, const float* ref_xyz, int32_t n);
 int icp_rmse(icp_ctx* ctx, const float pose[16], float* rmse_out);
+/* ConvergenceMeasure::benchmarkError (ConvergenceMeasure.h:104-151): mean |T s_i - r_i| / |T s_i - centroid(T s)|. */
+int icp_benchmark_error(icp_ctx* ctx, const float pose[16], float* error_out);
 
 /* -------- utils.h:106-133 on the device (used by the adaptor for transformPoints/Normals) -------- */
 int icp_transform_points(icp_ctx* ctx, const float* xyz, int32_t n, const float pose[16], float* out);
 int icp_transform_normals(icp_ctx* ctx, const float* normals, int32_t n, const float pose[16], float* out);
+
+/* The selection predicate of RANDOM_SAMPLING: point `index` is kept in resample number `iteration` iff the returned
+ * 32-bit hash is < proba * 2^32.  Exposed so host code (and the test oracle) can reproduce the device's choice exactly. */
+uint32_t icp_select_hash(uint32_t seed, uint32_t iteration, uint32_t index);
 
 /* Library identification: returns e.g. "icp_hip gfx950 <build id>". */
 const char* icp_version(void);

@@ -28,6 +28,7 @@
 #include <cstring>
 #include <iostream>
 #include <memory>
+#include <random>
 #include <stdexcept>
 #include <vector>
 
@@ -210,10 +211,11 @@ public:
     }
     // LinearICPOptimizer::estimatePose, ICPOptimizer.h:493-663
     void estimatePose(const PointCloud& source, const PointCloud& target, Matrix4f& initialPose, bool calculateRMSE = true) override {
-        if (selectionMethod != 0) {       // RANDOM_SAMPLING is seeded from random_device in the reference (selection.h:76-79)
-            std::cerr << "HipLinearICPOptimizer: only SELECT_ALL is supported on the device path" << std::endl; m_status = ICP_ERR_INVALID_ARG; return;
-        }
         icp_params p; icp_params_default(&p);
+        // RANDOM_SAMPLING: the reference seeds a fresh mt19937 from random_device per estimatePose (selection.h:76-79,
+        // ICPOptimizer.h:519-525); same here unless setSelectionSeed() pinned a seed for reproducible runs.
+        p.selection = (int32_t)selectionMethod; p.selection_proba = (float)proba;
+        p.selection_seed = m_seedPinned ? m_seed : (uint32_t)std::random_device{}();
         p.metric = (int32_t)metric; p.matching = (int32_t)matchingMethod; p.weighting = (int32_t)weightingMethod; p.rejection = (int32_t)rejectionMethod;
         p.color_icp = colorICP ? 1 : 0; p.multires = multiResolutionICP ? 1 : 0; p.n_iterations = (int32_t)m_nIterations; p.max_distance = maxDistance;
         p.knn_backend = ICP_KNN_LBVH;
@@ -255,10 +257,12 @@ public:
             for (int32_t i = 0; i < n; i++) { Matrix4f P; std::memcpy(P.data(), stats[(size_t)i].pose, sizeof(pose)); m_convergenceMeasure->recordAlignmentError(P); }
         }
     }
+    void setSelectionSeed(uint32_t seed) { m_seed = seed; m_seedPinned = true; }
     int lastStatus() const { return m_status; }
     const std::vector<icp_iter_stats>& iterations() const { return m_iterations; }
 private:
     icp_hip_detail::CtxPtr m_ctx; int m_status; bool m_hasCamera; float m_cam[4]; unsigned m_camW, m_camH;
+    uint32_t m_seed = 0; bool m_seedPinned = false;
     std::vector<icp_iter_stats> m_iterations;
 };
 

@@ -638,6 +638,24 @@ float orc_rmse(const float* src, const float* ref, int n, const float* pose) {
     return std::sqrt(rmse);
 }
 
+// ConvergenceMeasure::benchmarkError -> calculate_error, ConvergenceMeasure.h:104-151 (pcl::compute3DCentroid accumulates
+// in double and the centroid is narrowed to a float PointXYZ :113-114; pcl::euclideanDistance is an fp32 norm; the
+// quotient and the running sum are double :117-121).
+double orc_benchmark_error(const float* src, const float* ref, int n, const float* pose) {
+    std::vector<float> t((size_t)n * 3);
+    double c[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++) { xform_point(pose, src + (size_t)i*3, &t[(size_t)i*3]); for (int k = 0; k < 3; k++) c[k] += (double)t[(size_t)i*3+k]; }
+    float cf[3] = {(float)(c[0] / n), (float)(c[1] / n), (float)(c[2] / n)};
+    double error = 0;
+    for (int i = 0; i < n; i++) {
+        float e[3] = {t[(size_t)i*3] - ref[(size_t)i*3], t[(size_t)i*3+1] - ref[(size_t)i*3+1], t[(size_t)i*3+2] - ref[(size_t)i*3+2]};
+        float g[3] = {t[(size_t)i*3] - cf[0], t[(size_t)i*3+1] - cf[1], t[(size_t)i*3+2] - cf[2]};
+        double centroid_distance = std::sqrt(sqnorm3_tree(g));
+        error += (double)std::sqrt(sqnorm3_tree(e)) / centroid_distance;
+    }
+    return error / n;
+}
+
 // PointCloud::getCoarseResolution, PointCloud.h:325-343 : stride decimation keeping finite pts+normals.
 int orc_coarse(const float* pts, const float* nrm, const unsigned char* rgba, int n, int factor, float* opts, float* onrm, unsigned char* orgba, int* oidx) {
     int k = 0;
@@ -667,6 +685,9 @@ struct OrcParams {
     int window;          // 12                                       NearestNeighbor.h:319
     int knn_kdtree;      // oracle knob: 1 = exact kd-tree matcher (same results as the brute-force scan, faster)
     void* kdtree;        // cached tree handle (built by orc_estimate_pose / the caller)
+    int selection;       // 0 SELECT_ALL, 1 RANDOM_SAMPLING                      selection.h:9, ICPOptimizer.h:58-61
+    float selection_proba;
+    unsigned selection_seed;   // the reference seeds mt19937 from random_device (selection.h:76-79); see orc_select_hash
 };
 
 struct OrcIterRecord { int n_src; int n_valid; float pose[16]; double seconds_match; double seconds_rest; };
@@ -706,6 +727,14 @@ int orc_iterate(const OrcParams* prm, const float* sp0, const float* sn0, const 
     return 0;
 }
 
+// RANDOM_SAMPLING predicate.  selection.h:88-106 keeps point i iff ureal(rng) < prob with an mt19937 seeded from
+// random_device -- irreproducible by construction.  The contract shared with the device library is a counter-based hash
+// of (seed, resample number, original point index): kept iff hash < prob * 2^32.  Same distribution, reproducible.
+static inline unsigned orc_fmix32(unsigned h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16; return h; }
+unsigned orc_select_hash(unsigned seed, unsigned iteration, unsigned index) {
+    return orc_fmix32(index * 0x9E3779B9u + orc_fmix32(seed + iteration * 0x7F4A7C15u + 0x165667B1u));
+}
+
 // LinearICPOptimizer::estimatePose, ICPOptimizer.h:493-663 (SELECT_ALL only; RANDOM_SAMPLING is seeded
 // from random_device in the reference, selection.h:76-79, and is therefore out of parity scope).
 // records: capacity max_records; returns number of iterations run, or -1 on "no correspondences".
@@ -720,20 +749,34 @@ int orc_estimate_pose(const OrcParams* prm, const float* sp, const float* sn, co
     if (prm->multires) {                                          // :505-516
         while (1) { originalSize = (int)(originalSize / 2.0); if (originalSize < 100) break; currentResolution *= 2.0f; }
     }
-    std::vector<float> cp, cn; std::vector<unsigned char> cc;
+    std::vector<float> cp, cn; std::vector<unsigned char> cc; std::vector<int> cidx;
     const float* P0 = sp; const float* N0 = sn; const unsigned char* C0 = sc; int cur_n = n;
     auto decimate = [&](int factor) {
-        cp.assign((size_t)n*3, 0.f); cn.assign((size_t)n*3, 0.f); cc.assign((size_t)n*4, 0);
-        cur_n = orc_coarse(sp, sn, sc, n, factor, cp.data(), cn.data(), sc ? cc.data() : nullptr, nullptr);
+        cp.assign((size_t)n*3, 0.f); cn.assign((size_t)n*3, 0.f); cc.assign((size_t)n*4, 0); cidx.assign((size_t)n, 0);
+        cur_n = orc_coarse(sp, sn, sc, n, factor, cp.data(), cn.data(), sc ? cc.data() : nullptr, cidx.data());
         P0 = cp.data(); N0 = cn.data(); C0 = sc ? cc.data() : nullptr;
     };
+    std::vector<float> rp, rn; std::vector<unsigned char> rc8;
     if (prm->multires) decimate((int)currentResolution);          // :520-523
     int it = 0;
     for (int i = 0; i < prm->n_iterations || prm->multires; ++i) {   // :540
         int nv = 0; double tm = 0, tr = 0;
-        int rc = orc_iterate(prm, P0, N0, C0, cur_n, tp, tn, tc, m, pose, nullptr, &nv, &tm, &tr);
+        const float* Pi = P0; const float* Ni = N0; const unsigned char* Ci = C0; int ni = cur_n;
+        if (prm->selection == 1) {                               // sourceSelection.resample(), :549-550 / selection.h:88-106
+            double th = (double)prm->selection_proba * 4294967296.0;
+            rp.clear(); rn.clear(); rc8.clear();
+            for (int k = 0; k < cur_n; k++) {
+                const unsigned orig = (P0 == sp) ? (unsigned)k : (unsigned)cidx[k];
+                if (th >= 4294967296.0 || (th > 0.0 && orc_select_hash(prm->selection_seed, (unsigned)i, orig) < (unsigned)th)) {
+                    rp.insert(rp.end(), P0 + (size_t)k*3, P0 + (size_t)k*3 + 3); rn.insert(rn.end(), N0 + (size_t)k*3, N0 + (size_t)k*3 + 3);
+                    if (C0) rc8.insert(rc8.end(), C0 + (size_t)k*4, C0 + (size_t)k*4 + 4);
+                }
+            }
+            ni = (int)(rp.size() / 3); Pi = rp.data(); Ni = rn.data(); Ci = C0 ? rc8.data() : nullptr;
+        }
+        int rc = ni > 0 ? orc_iterate(prm, Pi, Ni, Ci, ni, tp, tn, tc, m, pose, nullptr, &nv, &tm, &tr) : 1;
         if (rc) return -1;
-        if (records && it < max_records) { records[it].n_src = cur_n; records[it].n_valid = nv; std::memcpy(records[it].pose, pose, 64); records[it].seconds_match = tm; records[it].seconds_rest = tr; }
+        if (records && it < max_records) { records[it].n_src = ni; records[it].n_valid = nv; std::memcpy(records[it].pose, pose, 64); records[it].seconds_match = tm; records[it].seconds_rest = tr; }
         it++;
         if (prm->multires) {                                      // :634-655
             if (currentResolution == 1.0f && i >= prm->n_iterations - 1) break;

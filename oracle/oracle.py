@@ -35,7 +35,8 @@ class Params(C.Structure):
     _fields_ = [("metric", C.c_int), ("matching", C.c_int), ("weighting", C.c_int), ("rejection", C.c_int),
                 ("color_icp", C.c_int), ("multires", C.c_int), ("n_iterations", C.c_int), ("solver_mode", C.c_int),
                 ("max_distance", C.c_float), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
-                ("width", C.c_int), ("height", C.c_int), ("window", C.c_int), ("knn_kdtree", C.c_int), ("kdtree", C.c_void_p)]
+                ("width", C.c_int), ("height", C.c_int), ("window", C.c_int), ("knn_kdtree", C.c_int), ("kdtree", C.c_void_p),
+                ("selection", C.c_int), ("selection_proba", C.c_float), ("selection_seed", C.c_uint)]
 
 
 class IterRecord(C.Structure):
@@ -44,7 +45,7 @@ class IterRecord(C.Structure):
 
 
 def make_params(metric=0, matching=0, weighting=0, rejection=1, color_icp=0, multires=0, n_iterations=20,
-                solver_mode=0, max_distance=0.0003, K=None, width=0, height=0, window=12, knn_kdtree=0):
+                solver_mode=0, max_distance=0.0003, K=None, width=0, height=0, window=12, knn_kdtree=0, selection=0, selection_proba=1.0, selection_seed=0):
     p = Params()
     p.metric, p.matching, p.weighting, p.rejection = metric, matching, weighting, rejection
     p.color_icp, p.multires, p.n_iterations, p.solver_mode = int(color_icp), int(multires), n_iterations, solver_mode
@@ -54,6 +55,7 @@ def make_params(metric=0, matching=0, weighting=0, rejection=1, color_icp=0, mul
         p.fx, p.fy, p.cx, p.cy = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
     p.width, p.height, p.window = width, height, window
     p.knn_kdtree = int(knn_kdtree); p.kdtree = None
+    p.selection, p.selection_proba, p.selection_seed = int(selection), float(selection_proba), int(selection_seed)
     return p
 
 
@@ -66,6 +68,8 @@ def lib():
         build()
         _lib = C.CDLL(_LIB)
         _lib.orc_rmse.restype = C.c_float
+        _lib.orc_select_hash.restype = C.c_uint
+        _lib.orc_benchmark_error.restype = C.c_double
         _lib.orc_kdtree_build.restype = C.c_void_p
     return _lib
 
@@ -213,6 +217,15 @@ def solve_symmetric(s, d, ns, nt, w, mode=0):
 def rmse(src, ref, pose):
     src, ref = _f32(src), _f32(ref)
     return float(lib().orc_rmse(_p(src), _p(ref), C.c_int(len(src)), _p(_pose_c(pose))))
+
+
+def benchmark_error(src, ref, pose):
+    src, ref = _f32(src), _f32(ref)
+    return float(lib().orc_benchmark_error(_p(src), _p(ref), C.c_int(len(src)), _p(_pose_c(pose))))
+
+
+def select_hash(seed, iteration, index):
+    return int(lib().orc_select_hash(C.c_uint(seed), C.c_uint(iteration), C.c_uint(index)))
 
 
 def coarse(pts, nrm, rgba, factor):

@@ -12,7 +12,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 def header_functions():
     txt = open(os.path.join(ROOT, "include", "icp_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"^\s*(?:int|const char\s*\*)\s+(icp_\w+)\s*\(", txt, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|uint32_t|const char\s*\*)\s+(icp_\w+)\s*\(", txt, flags=re.M)))
 
 
 def test_header_and_binding_agree():
@@ -47,8 +47,8 @@ def test_params_default_match_reference_ctor():
 
 def test_struct_layouts():
     from icp_amd import binding
-    assert ctypes.sizeof(binding.IcpParams) == 16 * 4
-    assert ctypes.sizeof(binding.IcpIterStats) == 4 + 4 + 64 + 4 + 4
+    assert ctypes.sizeof(binding.IcpParams) == 19 * 4
+    assert ctypes.sizeof(binding.IcpIterStats) == 4 + 4 + 64 + 4 + 4 + 4
     assert binding.MATCH_DTYPE.itemsize == 8            # struct Match, NearestNeighbor.h:7-10
 
 

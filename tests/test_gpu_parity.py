@@ -342,3 +342,57 @@ def test_context_reuse_across_pairs(gpu_ctx_factory, orc, bunny, small_pair):
     c.set_target(p["tgt_pts"], p["tgt_nrm"]); c.set_source(p["src_pts"], p["src_nrm"])
     b, _, _ = c.run(np.eye(4))
     assert np.array_equal(a, b)                                          # deterministic, bit-identical rerun
+
+
+def test_benchmark_error_matches_oracle(gpu_ctx_factory, orc, small_pair):
+    """ConvergenceMeasure::benchmarkError (ConvergenceMeasure.h:104-151), the Fontana-style ETH metric, on the device."""
+    from icp_amd import binding
+    p = small_pair
+    c = gpu_ctx_factory()
+    c.set_convergence_reference(p["src_pts"], p["src_unperturbed"])
+    for T in (np.eye(4, dtype=f32), p["gt"].astype(f32), rand_pose(4)):
+        a, b = c.benchmark_error(T), orc.benchmark_error(p["src_pts"], p["src_unperturbed"], T)
+        assert abs(a - b) <= 2e-6 * max(1.0, abs(b)), (a, b)
+    # per-iteration recording like alignETH (main.cpp:439-444): ConvergenceMeasure(source, original_source, true)
+    opt = binding.LinearICPOptimizer(0)
+    opt.setMatchingMaxDistance(10.0); opt.setMetric(1); opt.setNbOfIterations(6)
+    opt.setConvergenceMeasure(p["src_pts"], p["src_unperturbed"], runBenchmark=True)
+    pose, recs = opt.estimatePose(dict(pts=p["src_pts"], nrm=p["src_nrm"]), dict(pts=p["tgt_pts"], nrm=p["tgt_nrm"]), np.eye(4))
+    errs = [r["benchmark_error"] for r in recs]
+    assert errs[-1] < 0.2 * orc.benchmark_error(p["src_pts"], p["src_unperturbed"], np.eye(4))     # ICP undoes the perturbation
+    assert abs(errs[-1] - orc.benchmark_error(p["src_pts"], p["src_unperturbed"], pose)) < 2e-6
+    assert all(r["rmse"] > 0 for r in recs)
+    opt.ctx.close()
+
+
+@pytest.mark.parametrize("metric,multires", [(0, 0), (1, 0), (2, 0), (1, 1)])
+def test_random_selection_run_matches_oracle(gpu_ctx_factory, orc, bunny, metric, multires):
+    """RANDOM_SAMPLING rows of Data/bunny_experiments.csv (bunny103-105: proba 0.5) with an explicit seed: the device draws
+    the same samples as the oracle (identical per-iteration sizes) and lands on the same pose."""
+    from conftest import pose_error
+    from icp_amd import binding
+    opt = binding.LinearICPOptimizer(0)
+    opt.setMatchingMaxDistance(0.0003); opt.setMetric(metric); opt.setNbOfIterations(20); opt.enableMultiResolution(bool(multires))
+    opt.setSelectionMethod(1, 0.5, seed=1234)
+    pose, recs = opt.estimatePose(dict(pts=bunny["src_pts"], nrm=bunny["src_nrm"]), dict(pts=bunny["tgt_pts"], nrm=bunny["tgt_nrm"]), np.eye(4))
+    prm = orc.make_params(metric=metric, multires=multires, n_iterations=20, max_distance=0.0003, solver_mode=1, selection=1, selection_proba=0.5, selection_seed=1234)
+    po, ro = orc.estimate_pose(prm, bunny["src_pts"], bunny["src_nrm"], None, bunny["tgt_pts"], bunny["tgt_nrm"], None, np.eye(4))
+    assert [r["n_src"] for r in recs] == [r["n_src"] for r in ro]
+    assert [r["n_valid"] for r in recs][:5] == [r["n_valid"] for r in ro][:5]
+    ang, tr = pose_error(pose, po)
+    assert ang < POSE_TOL and tr < POSE_TOL
+    opt.ctx.close()
+
+
+def test_random_selection_extremes(gpu_ctx_factory, bunny):
+    from icp_amd import binding
+    c = gpu_ctx_factory()
+    c.params.max_distance = 0.0003; c.params.metric = 1; c.params.n_iterations = 3; c.params.selection = 1; c.params.selection_proba = 1.0; c.push_params()
+    c.set_target(bunny["tgt_pts"], bunny["tgt_nrm"]); c.set_source(bunny["src_pts"], bunny["src_nrm"])
+    a, ra, _ = c.run(np.eye(4))
+    c.params.selection = 0; c.push_params()
+    b, rb, _ = c.run(np.eye(4))
+    assert np.array_equal(a, b) and [r["n_src"] for r in ra] == [1054] * 3
+    c.params.selection = 1; c.params.selection_proba = 0.0; c.push_params()
+    pose, recs, rc = c.run(np.eye(4), check=False)
+    assert rc == binding.ERR_NO_CORRESPONDENCES and all(r["n_src"] == 0 for r in recs)

@@ -334,6 +334,38 @@ def test_rmse(orc):
     assert abs(v - np.sqrt(3) * 0.01) < 1e-5
 
 
+def test_random_selection_contract(orc, bunny):
+    """RANDOM_SAMPLING (selection.h:88-106) with the reproducible hash predicate: library == oracle, Bernoulli(p) statistics,
+    resampled every iteration, and ICP still converges on a 50 % sample (Data/bunny_experiments.csv rows bunny103-105)."""
+    from icp_amd import binding
+    idx = np.arange(20000)
+    h = np.array([orc.select_hash(7, 3, int(i)) for i in idx[:2000]], np.uint64)
+    assert all(binding.select_hash(7, 3, int(i)) == int(h[i]) for i in range(0, 2000, 97))
+    frac = (h < 0.3 * 2 ** 32).mean()
+    assert abs(frac - 0.3) < 0.04
+    assert orc.select_hash(7, 3, 5) != orc.select_hash(7, 4, 5) and orc.select_hash(7, 3, 5) != orc.select_hash(8, 3, 5)
+    sp, sn, tp, tn = bunny["src_pts"], bunny["src_nrm"], bunny["tgt_pts"], bunny["tgt_nrm"]
+    prm = orc.make_params(metric=1, n_iterations=20, max_distance=0.0003, selection=1, selection_proba=0.5, selection_seed=11)
+    pose, recs = orc.estimate_pose(prm, sp, sn, None, tp, tn, None, np.eye(4))
+    ns = [r["n_src"] for r in recs]
+    assert len(set(ns)) > 5 and all(400 < v < 660 for v in ns)            # a fresh ~50 % sample per iteration
+    gs = sp[bunny["gt_src_idx"]]; gt = tp[bunny["gt_tgt_idx"]]
+    assert orc.rmse(gs, gt, pose) < 2e-3
+    prm1 = orc.make_params(metric=1, n_iterations=5, max_distance=0.0003, selection=1, selection_proba=1.0)
+    prm0 = orc.make_params(metric=1, n_iterations=5, max_distance=0.0003)
+    assert np.array_equal(orc.estimate_pose(prm1, sp, sn, None, tp, tn, None, np.eye(4))[0], orc.estimate_pose(prm0, sp, sn, None, tp, tn, None, np.eye(4))[0])
+
+
+def test_benchmark_error(orc):
+    """ConvergenceMeasure.h:104-151: mean |T s - r| / |T s - centroid(T s)|."""
+    rng = np.random.default_rng(12)
+    s = rng.uniform(-3, 3, (500, 3)).astype(f32); T = rand_pose(rng)
+    r = (s + rng.normal(0, 0.01, s.shape)).astype(f32)
+    t = orc.transform_points(s, T).astype(np.float64)
+    exp = np.mean(np.linalg.norm(t - r, axis=1) / np.linalg.norm(t - t.mean(0), axis=1))
+    assert abs(orc.benchmark_error(s, r, T) - exp) < 1e-6 * exp
+
+
 def test_golden_regression(orc, bunny, bunny_oracle):
     """The committed vectors (tests/golden/bunny_oracle.npz) are reproduced by the oracle as built here."""
     sp, sn, sc, tp, tn, tc = [bunny[k] for k in ("src_pts", "src_nrm", "src_rgba", "tgt_pts", "tgt_nrm", "tgt_rgba")]
