@@ -1225,6 +1225,49 @@ __global__ __launch_bounds__(256) void k_select_scatter(const int* __restrict__ 
     if (keep) out[off + rank] = i;
 }
 
+// PointCloud(depthMap, colorFrame, K, extrinsics, width, height, ...) (PointCloud.h:78-165): back-projection of a depth
+// image and central-difference normals, the step in front of the ICP loop for RGB-D input.  One lane = one pixel; output is
+// organised (invalid = MINF), `valid` marks what the keepOriginalSize = false filter keeps (:148-152).
+// Quirks kept: normals are NOT rotated by the extrinsics (:128-129); the colour of pixel i is read from bytes i..i+3 of the
+// RGBX frame instead of 4i..4i+3 (:156-157) unless fix_color_index is set.
+__global__ void k_backproject(const float* __restrict__ depth, const uint8_t* __restrict__ rgbx, int width, int height,
+                              float fx, float fy, float cx, float cy, const float* __restrict__ inv /* 3x3 row-major R^-1, then t^-1 */,
+                              float max_distance_halved, int fix_color_index,
+                              float* __restrict__ xyz, float* __restrict__ nrm, uint8_t* __restrict__ rgba, uint8_t* __restrict__ valid) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = width * height;
+    if (idx >= n) return;
+    const int v = idx / width, u = idx - v * width;
+    const float d = depth[idx];
+    float p0 = -INFINITY, p1 = -INFINITY, p2 = -INFINITY;
+    if (d != -INFINITY) {                                           // :104-110
+        const float a = ((float)u - cx) / fx * d, b = ((float)v - cy) / fy * d, c = d;
+        p0 = (inv[0] * a + (inv[1] * b + inv[2] * c)) + inv[9];
+        p1 = (inv[3] * a + (inv[4] * b + inv[5] * c)) + inv[10];
+        p2 = (inv[6] * a + (inv[7] * b + inv[8] * c)) + inv[11];
+    }
+    float n0 = -INFINITY, n1 = -INFINITY, n2 = -INFINITY;
+    if (v >= 1 && v < height - 1 && u >= 1 && u < width - 1) {      // :117-131, borders stay MINF (:134-141)
+        const float du = 0.5f * (depth[idx + 1] - depth[idx - 1]);
+        const float dv = 0.5f * (depth[idx + width] - depth[idx - width]);
+        if (isfinite(du) && isfinite(dv) && !(fabsf(du) > max_distance_halved) && !(fabsf(dv) > max_distance_halved)) {
+            const float x = -du, y = -dv, z = 1.f;
+            const float sq = x * x + (y * y + z * z);
+            const float len = sqrtf(sq);
+            n0 = x / len; n1 = y / len; n2 = z / len;
+        }
+    }
+    xyz[(size_t)idx * 3] = p0; xyz[(size_t)idx * 3 + 1] = p1; xyz[(size_t)idx * 3 + 2] = p2;
+    nrm[(size_t)idx * 3] = n0; nrm[(size_t)idx * 3 + 1] = n1; nrm[(size_t)idx * 3 + 2] = n2;
+    if (rgba && rgbx) {
+        const size_t base = fix_color_index ? (size_t)idx * 4 : (size_t)idx;
+        const size_t last = (size_t)n * 4 - 1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) rgba[(size_t)idx * 4 + k] = rgbx[base + k <= last ? base + k : last];
+    }
+    if (valid) valid[idx] = (finite3(p0, p1, p2) && finite3(n0, n1, n2)) ? 1 : 0;
+}
+
 // utils.h:106-133 as stand-alone kernels for the adaptor's transformPoints / transformNormals
 __global__ void k_transform_aos(const float* __restrict__ in, int n, const PoseState* __restrict__ ps, int normals, float* __restrict__ out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -774,6 +774,42 @@ int icp_rmse(icp_ctx* c, const float pose[16], float* rmse_out) {
     return ICP_OK;
 }
 
+int icp_backproject_depth(icp_ctx* c, const float* depth, const uint8_t* rgbx, float fx, float fy, float cx, float cy,
+                          const float extrinsics[16], int32_t width, int32_t height, float max_distance, int32_t fix_color_index,
+                          float* xyz_out, float* normals_out, uint8_t* rgba_out, uint8_t* valid_out) {
+    if (!c || !depth || !extrinsics || !xyz_out || !normals_out || width <= 0 || height <= 0) { if (c) c->err = "icp_backproject_depth: bad argument"; return ICP_ERR_INVALID_ARG; }
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    const size_t n = (size_t)width * height;
+    // depthExtrinsics.inverse() (PointCloud.h:88-90): rigid/affine 4x4, inverted in fp64 and rounded once
+    double R[9], t[3];
+    for (int r = 0; r < 3; r++) { for (int k = 0; k < 3; k++) R[r * 3 + k] = extrinsics[k * 4 + r]; t[r] = extrinsics[12 + r]; }
+    const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+    double Ri[9] = {(R[4] * R[8] - R[5] * R[7]) / det, (R[2] * R[7] - R[1] * R[8]) / det, (R[1] * R[5] - R[2] * R[4]) / det,
+                    (R[5] * R[6] - R[3] * R[8]) / det, (R[0] * R[8] - R[2] * R[6]) / det, (R[2] * R[3] - R[0] * R[5]) / det,
+                    (R[3] * R[7] - R[4] * R[6]) / det, (R[1] * R[6] - R[0] * R[7]) / det, (R[0] * R[4] - R[1] * R[3]) / det};
+    float inv[12];
+    for (int i = 0; i < 9; i++) inv[i] = (float)Ri[i];
+    for (int r = 0; r < 3; r++) inv[9 + r] = (float)(-(Ri[r * 3] * t[0] + Ri[r * 3 + 1] * t[1] + Ri[r * 3 + 2] * t[2]));
+    const size_t bytes = n * 4 + (rgbx ? n * 4 : 0) + 64 + n * 12 * 2 + n * 4 + n;
+    if ((rc = ensure(c, c->staging, bytes + 256))) return rc;
+    char* base = c->staging.as<char>();
+    float* d_depth = (float*)base; uint8_t* d_rgbx = (uint8_t*)(base + n * 4); float* d_inv = (float*)(base + n * 8);
+    float* d_xyz = (float*)(base + n * 8 + 64); float* d_nrm = d_xyz + n * 3; uint8_t* d_rgba = (uint8_t*)(d_nrm + n * 3); uint8_t* d_valid = d_rgba + n * 4;
+    HIPCK(c, hipMemcpyAsync(d_depth, depth, n * 4, hipMemcpyHostToDevice, c->stream));
+    if (rgbx) HIPCK(c, hipMemcpyAsync(d_rgbx, rgbx, n * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(d_inv, inv, sizeof(inv), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_backproject, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, d_depth, rgbx ? d_rgbx : nullptr, width, height, fx, fy, cx, cy, d_inv,
+                       max_distance / 2.f, fix_color_index, d_xyz, d_nrm, (rgbx && rgba_out) ? d_rgba : nullptr, valid_out ? d_valid : nullptr);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(xyz_out, d_xyz, n * 12, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(normals_out, d_nrm, n * 12, hipMemcpyDeviceToHost, c->stream));
+    if (rgbx && rgba_out) HIPCK(c, hipMemcpyAsync(rgba_out, d_rgba, n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (valid_out) HIPCK(c, hipMemcpyAsync(valid_out, d_valid, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return ICP_OK;
+}
+
 static int transform_common(icp_ctx* c, const float* in, int32_t n, const float pose[16], float* out, int normals) {
     if (!c || !in || !out || !pose || n <= 0) { if (c) c->err = "icp_transform: bad argument"; return ICP_ERR_INVALID_ARG; }
     int rc;

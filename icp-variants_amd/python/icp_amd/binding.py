@@ -50,7 +50,7 @@ class IcpTiming(C.Structure):
 EXPORTS = ["icp_ctx_create", "icp_ctx_create_on_stream", "icp_ctx_destroy", "icp_last_error", "icp_params_default",
            "icp_set_params", "icp_get_params", "icp_set_target", "icp_set_source", "icp_query_matches", "icp_match",
            "icp_correspond", "icp_iterate", "icp_run", "icp_get_timing", "icp_set_convergence_reference", "icp_rmse", "icp_benchmark_error",
-           "icp_transform_points", "icp_transform_normals", "icp_version", "icp_schedule", "icp_select_hash"]
+           "icp_transform_points", "icp_transform_normals", "icp_version", "icp_schedule", "icp_select_hash", "icp_backproject_depth"]
 
 _lib = None
 
@@ -202,6 +202,18 @@ class Context:
         out = C.c_float(0)
         self._ck(self.lib.icp_benchmark_error(self.h, _ptr(pose_to_c(pose)), C.byref(out)))
         return out.value
+
+    def backproject_depth(self, depth, rgbx, K, extrinsics=None, max_distance=0.1, fix_color_index=False):
+        """PointCloud(depthMap, colorFrame, K, extrinsics, w, h, keepOriginalSize=true) on the device (PointCloud.h:78-165)."""
+        depth = np.ascontiguousarray(depth, dtype=np.float32); h, w = depth.shape
+        K = np.asarray(K, dtype=np.float32); E = pose_to_c(np.eye(4) if extrinsics is None else extrinsics)
+        rgbx = None if rgbx is None else np.ascontiguousarray(rgbx, dtype=np.uint8)
+        xyz = np.empty((h * w, 3), np.float32); nrm = np.empty((h * w, 3), np.float32)
+        rgba = np.empty((h * w, 4), np.uint8) if rgbx is not None else None; valid = np.empty(h * w, np.uint8)
+        self._ck(self.lib.icp_backproject_depth(self.h, _ptr(depth), _ptr(rgbx), C.c_float(K[0, 0]), C.c_float(K[1, 1]), C.c_float(K[0, 2]), C.c_float(K[1, 2]),
+                                                _ptr(E), C.c_int32(w), C.c_int32(h), C.c_float(max_distance), C.c_int32(int(fix_color_index)),
+                                                _ptr(xyz), _ptr(nrm), _ptr(rgba), _ptr(valid)))
+        return xyz, nrm, rgba, valid.astype(bool)
 
     def transform_points(self, xyz, pose):
         x = _f32(xyz); out = np.empty_like(x)

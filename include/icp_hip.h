@@ -148,6 +148,17 @@ int icp_benchmark_error(icp_ctx* ctx, const float pose[16], float* error_out);
 int icp_transform_points(icp_ctx* ctx, const float* xyz, int32_t n, const float pose[16], float* out);
 int icp_transform_normals(icp_ctx* ctx, const float* normals, int32_t n, const float pose[16], float* out);
 
+/* -------- pre-processing in front of the loop --------
+ * PointCloud(float* depthMap, BYTE* colorFrame, depthIntrinsics, depthExtrinsics, width, height, keepOriginalSize, ...)
+ * (PointCloud.h:78-165): back-projects a depth image (MINF = no measurement, VirtualSensor.h:119-124) and computes
+ * central-difference normals on the device.  Outputs are organised, width*height entries, invalid entries MINF
+ * (= keepOriginalSize true, downsampleFactor 1); valid_out (optional) marks the entries the keepOriginalSize = false
+ * filter keeps.  rgbx / rgba_out may be NULL.  fix_color_index = 0 reproduces the reference's colour indexing
+ * (bytes i..i+3 of the RGBX frame for pixel i, PointCloud.h:156-157), 1 reads pixel i's own 4 bytes. */
+int icp_backproject_depth(icp_ctx* ctx, const float* depth, const uint8_t* rgbx, float fx, float fy, float cx, float cy,
+                          const float extrinsics[16], int32_t width, int32_t height, float max_distance, int32_t fix_color_index,
+                          float* xyz_out, float* normals_out, uint8_t* rgba_out, uint8_t* valid_out);
+
 /* The selection predicate of RANDOM_SAMPLING: point `index` is kept in resample number `iteration` iff the returned
  * 32-bit hash is < proba * 2^32.  Exposed so host code (and the test oracle) can reproduce the device's choice exactly. */
 uint32_t icp_select_hash(uint32_t seed, uint32_t iteration, uint32_t index);

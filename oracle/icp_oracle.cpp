@@ -656,6 +656,40 @@ double orc_benchmark_error(const float* src, const float* ref, int n, const floa
     return error / n;
 }
 
+// PointCloud(float* depthMap, BYTE* colorFrame, K, extrinsics, width, height, keepOriginalSize = true), PointCloud.h:78-165.
+// inv: 3x3 row-major inverse rotation followed by the inverse translation (12 floats), supplied by the caller.
+void orc_backproject(const float* depth, const unsigned char* rgbx, int width, int height, float fx, float fy, float cx, float cy, const float* inv,
+                     float max_distance, int fix_color_index, float* xyz, float* nrm, unsigned char* rgba, unsigned char* valid) {
+    const float half = max_distance / 2.f;                          // :85
+    const int n = width * height;
+    for (int v = 0; v < height; v++) for (int u = 0; u < width; u++) {
+        const int idx = v * width + u;
+        float* p = xyz + (size_t)idx*3; float* q = nrm + (size_t)idx*3;
+        const float d = depth[idx];
+        if (d == MINF_) { p[0] = p[1] = p[2] = MINF_; }                // :104-106
+        else {
+            float c[3] = {(u - cx) / fx * d, (v - cy) / fy * d, d};    // :109
+            for (int r = 0; r < 3; r++) p[r] = (inv[r*3] * c[0] + (inv[r*3+1] * c[1] + inv[r*3+2] * c[2])) + inv[9 + r];
+        }
+        q[0] = q[1] = q[2] = MINF_;
+        if (v >= 1 && v < height - 1 && u >= 1 && u < width - 1) {     // :117-131
+            const float du = 0.5f * (depth[idx + 1] - depth[idx - 1]);
+            const float dv = 0.5f * (depth[idx + width] - depth[idx - width]);
+            if (std::isfinite(du) && std::isfinite(dv) && !(std::fabs(du) > half) && !(std::fabs(dv) > half)) {
+                float nn[3] = {-du, -dv, 1.f};
+                const float len = std::sqrt(sqnorm3_tree(nn));        // normalize(), :129
+                q[0] = nn[0] / len; q[1] = nn[1] / len; q[2] = nn[2] / len;
+            }
+        }
+        if (rgba && rgbx) {
+            const size_t base = fix_color_index ? (size_t)idx * 4 : (size_t)idx;      // :156-157 reads colorFrame[i .. i+3]
+            const size_t last = (size_t)n * 4 - 1;
+            for (int k = 0; k < 4; k++) rgba[(size_t)idx*4 + k] = rgbx[base + k <= last ? base + k : last];
+        }
+        if (valid) valid[idx] = (finite3(p) && finite3(q)) ? 1 : 0;     // :152
+    }
+}
+
 // PointCloud::getCoarseResolution, PointCloud.h:325-343 : stride decimation keeping finite pts+normals.
 int orc_coarse(const float* pts, const float* nrm, const unsigned char* rgba, int n, int factor, float* opts, float* onrm, unsigned char* orgba, int* oidx) {
     int k = 0;

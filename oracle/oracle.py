@@ -228,6 +228,20 @@ def select_hash(seed, iteration, index):
     return int(lib().orc_select_hash(C.c_uint(seed), C.c_uint(iteration), C.c_uint(index)))
 
 
+def backproject(depth, rgbx, K, extrinsics=None, max_distance=0.1, fix_color_index=False):
+    depth = np.ascontiguousarray(depth, dtype=np.float32); h, w = depth.shape
+    K = np.asarray(K, dtype=np.float32)
+    E = np.eye(4) if extrinsics is None else np.asarray(extrinsics, np.float64)
+    Ei = np.linalg.inv(E)
+    inv = np.concatenate([Ei[:3, :3].reshape(9), Ei[:3, 3]]).astype(np.float32)
+    rgbx = _u8(rgbx)
+    xyz = np.empty((h * w, 3), np.float32); nrm = np.empty((h * w, 3), np.float32)
+    rgba = np.empty((h * w, 4), np.uint8) if rgbx is not None else None; valid = np.empty(h * w, np.uint8)
+    lib().orc_backproject(_p(depth), _p(rgbx), C.c_int(w), C.c_int(h), C.c_float(K[0, 0]), C.c_float(K[1, 1]), C.c_float(K[0, 2]), C.c_float(K[1, 2]),
+                          _p(inv), C.c_float(max_distance), C.c_int(int(fix_color_index)), _p(xyz), _p(nrm), _p(rgba), _p(valid))
+    return xyz, nrm, rgba, valid.astype(bool)
+
+
 def coarse(pts, nrm, rgba, factor):
     pts, nrm = _f32(pts), _f32(nrm); n = len(pts)
     op = np.empty((n, 3), np.float32); on = np.empty((n, 3), np.float32); oi = np.empty(n, np.int32)

@@ -70,3 +70,46 @@ def test_fullsize_run_converges_and_is_deterministic(eth_ctx, eth_pair):
     assert ang < 2e-3 and tr < 5e-3
     t = eth_ctx.timing()
     assert t["iterations"] == 50 and t["match_ms"] > 0
+
+
+def test_fullsize_projective_tum_geometry(gpu_ctx_factory, orc):
+    """configs[2] at native TUM geometry (640 x 480, K from VirtualSensor.h:44-46): projective matches bit-exact vs the oracle
+    over all 307 200 queries, then the symmetric ICP run registers the frames."""
+    from conftest import pose_error
+    from icp_amd import synth
+    r = synth.rgbd_pair(0)
+    W, H, K = r["width"], r["height"], r["K"]
+    c = gpu_ctx_factory()
+    c.params.matching = 1; c.params.metric = 2; c.params.max_distance = 0.1; c.params.n_iterations = 35            # main.cpp:226-228,245
+    c.params.fx, c.params.fy, c.params.cx, c.params.cy, c.params.width, c.params.height = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), W, H
+    c.push_params(); c.set_target(r["tgt_pts"], r["tgt_nrm"]); c.set_source(r["src_pts"], r["src_nrm"])
+    assert len(r["src_pts"]) == 307200
+    for T in (np.eye(4, dtype=f32), r["gt"].astype(f32)):
+        m, d2 = c.match(T)
+        mo, do = orc.projective(orc.transform_points(r["src_pts"], T), r["tgt_pts"], W, H, K, 0.1)
+        assert np.array_equal(m["idx"], mo["idx"]) and np.array_equal(d2.view(np.uint32), do.view(np.uint32))
+    pose, recs, _ = c.run(np.eye(4))
+    ang, tr = pose_error(pose, r["gt"])
+    assert ang < 1e-3 and tr < 2e-3 and len(recs) == 35
+
+
+def test_fullsize_colour_knn_tum_geometry(gpu_ctx_factory, orc):
+    """configs[4] shape: 6-D k-NN over ~290k valid target pixels; a 16k-query subsample is checked bit-exact against the
+    oracle's 6-D scan, the multires colour-ICP run against the ground-truth motion."""
+    from conftest import pose_error
+    from icp_amd import synth
+    r = synth.rgbd_pair(0)
+    tp, tn, tc = synth.compact_valid(r["tgt_pts"], r["tgt_nrm"], r["tgt_rgba"])
+    sp, sn, sc = r["src_pts"], r["src_nrm"], r["src_rgba"]
+    c = gpu_ctx_factory()
+    c.params.color_icp = 1; c.params.weighting = 3; c.params.multires = 1; c.params.metric = 1; c.params.max_distance = 0.1
+    c.params.n_iterations = 35; c.params.knn_backend = 1
+    c.push_params(); c.set_target(tp, tn, tc); c.set_source(sp, sn, sc)
+    m, d2 = c.match(np.eye(4))
+    sub = np.random.default_rng(1).choice(len(sp), 16384, replace=False)
+    mo, do = orc.knn6(sp[sub], sc[sub], tp, tc, 0.1)
+    assert np.array_equal(m["idx"][sub], mo["idx"]) and np.array_equal(d2[sub].view(np.uint32), do.view(np.uint32))
+    pose, recs, _ = c.run(np.eye(4))
+    assert [x["n_src"] for x in recs][0] < 300 and recs[-1]["n_src"] > 250000          # coarse-to-fine schedule ran
+    ang, tr = pose_error(pose, r["gt"])
+    assert ang < 2e-3 and tr < 5e-3

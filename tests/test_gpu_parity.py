@@ -396,3 +396,21 @@ def test_random_selection_extremes(gpu_ctx_factory, bunny):
     c.params.selection = 1; c.params.selection_proba = 0.0; c.push_params()
     pose, recs, rc = c.run(np.eye(4), check=False)
     assert rc == binding.ERR_NO_CORRESPONDENCES and all(r["n_src"] == 0 for r in recs)
+
+
+def test_backproject_depth_bit_exact(gpu_ctx_factory, orc):
+    """PointCloud(depthMap, colorFrame, ...) on the device == oracle, bit for bit (PointCloud.h:78-165), TUM geometry."""
+    from icp_amd import synth
+    W, H = 640, 480
+    K = np.array([[525.0, 0, 319.5], [0, 525.0, 239.5], [0, 0, 1]], f32)                 # VirtualSensor.h:44-46
+    r = synth.rgbd_pair(0)
+    depth = r["tgt_pts"][:, 2].reshape(H, W).copy()                                       # z of the organised camera-frame cloud = depth, holes MINF
+    rgbx = r["tgt_rgba"]
+    c = gpu_ctx_factory()
+    for E, fix in ((None, False), (synth.make_pose((0.02, -0.01, 0.03), (0.1, 0.2, -0.1)), True)):
+        g = c.backproject_depth(depth, rgbx, K, extrinsics=E, fix_color_index=fix)
+        o = orc.backproject(depth, rgbx, K, extrinsics=E, fix_color_index=fix)
+        assert np.array_equal(g[0].view(np.uint32), o[0].view(np.uint32))
+        assert np.array_equal(g[1].view(np.uint32), o[1].view(np.uint32))
+        assert np.array_equal(g[2], o[2]) and np.array_equal(g[3], o[3])
+    assert 0.7 < g[3].mean() < 1.0
