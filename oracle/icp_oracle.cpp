@@ -656,6 +656,19 @@ double orc_benchmark_error(const float* src, const float* ref, int n, const floa
     return error / n;
 }
 
+// depthExtrinsics.inverse() (PointCloud.h:88-90).  Eigen's fp32 4x4 inverse is not reproducible without Eigen; the contract
+// shared with the device library is the fp64 cofactor inverse of the affine [R|t] (column-major fp32 input) rounded once.
+void orc_invert_extrinsics(const float* E /* column-major 4x4 */, float* inv12 /* R^-1 row-major (9), then -R^-1 t (3) */) {
+    double R[9], t[3];
+    for (int r = 0; r < 3; r++) { for (int k = 0; k < 3; k++) R[r*3+k] = E[k*4+r]; t[r] = E[12+r]; }
+    const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+    double Ri[9] = {(R[4] * R[8] - R[5] * R[7]) / det, (R[2] * R[7] - R[1] * R[8]) / det, (R[1] * R[5] - R[2] * R[4]) / det,
+                    (R[5] * R[6] - R[3] * R[8]) / det, (R[0] * R[8] - R[2] * R[6]) / det, (R[2] * R[3] - R[0] * R[5]) / det,
+                    (R[3] * R[7] - R[4] * R[6]) / det, (R[1] * R[6] - R[0] * R[7]) / det, (R[0] * R[4] - R[1] * R[3]) / det};
+    for (int i = 0; i < 9; i++) inv12[i] = (float)Ri[i];
+    for (int r = 0; r < 3; r++) inv12[9 + r] = (float)(-(Ri[r*3] * t[0] + Ri[r*3+1] * t[1] + Ri[r*3+2] * t[2]));
+}
+
 // PointCloud(float* depthMap, BYTE* colorFrame, K, extrinsics, width, height, keepOriginalSize = true), PointCloud.h:78-165.
 // inv: 3x3 row-major inverse rotation followed by the inverse translation (12 floats), supplied by the caller.
 void orc_backproject(const float* depth, const unsigned char* rgbx, int width, int height, float fx, float fy, float cx, float cy, const float* inv,

@@ -231,9 +231,8 @@ def select_hash(seed, iteration, index):
 def backproject(depth, rgbx, K, extrinsics=None, max_distance=0.1, fix_color_index=False):
     depth = np.ascontiguousarray(depth, dtype=np.float32); h, w = depth.shape
     K = np.asarray(K, dtype=np.float32)
-    E = np.eye(4) if extrinsics is None else np.asarray(extrinsics, np.float64)
-    Ei = np.linalg.inv(E)
-    inv = np.concatenate([Ei[:3, :3].reshape(9), Ei[:3, 3]]).astype(np.float32)
+    inv = np.empty(12, np.float32)
+    lib().orc_invert_extrinsics(_p(_pose_c(np.eye(4) if extrinsics is None else extrinsics)), _p(inv))
     rgbx = _u8(rgbx)
     xyz = np.empty((h * w, 3), np.float32); nrm = np.empty((h * w, 3), np.float32)
     rgba = np.empty((h * w, 4), np.uint8) if rgbx is not None else None; valid = np.empty(h * w, np.uint8)
