@@ -511,6 +511,96 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, con
     if (kp.d2_out) kp.d2_out[k] = best;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Surface normals from the K nearest neighbours (the PCL NormalEstimation the reference runs on the ETH scans,
+// PointCloud.h:41-76: setKSearch(5), viewpoint (0,0,0)): K-NN over the cloud's own kd-ordered BVH (the point itself is its
+// first neighbour, as with pcl::search::KdTree), fp64 covariance of the K points, eigenvector of the smallest eigenvalue
+// (fp64 Jacobi), flipped towards the viewpoint (pcl::flipNormalTowardsViewpoint), curvature = l0 / (l0 + l1 + l2).
+// Neighbour sets are the exact K smallest (d2, index) pairs.  PCL itself is absent here: parity unpinned, checked against numpy.
+template <int n> __device__ inline void jacobi_eig_sym(double* A, double* V, double* ev);     // defined with the solvers below
+
+template <int K>
+__device__ __forceinline__ void knn_insert(float (&bd)[K], int (&bj)[K], float d, int j) {
+    // keep (bd, bj) sorted ascending by (d, j); called only when (d, j) beats the current worst
+    bd[K - 1] = d; bj[K - 1] = j;
+#pragma unroll
+    for (int q = K - 1; q > 0; q--) {
+        const bool sw = (bd[q] < bd[q - 1]) | ((bd[q] == bd[q - 1]) & (bj[q] < bj[q - 1]));
+        const float td = bd[q]; const int tj = bj[q];
+        bd[q] = sw ? bd[q - 1] : bd[q]; bj[q] = sw ? bj[q - 1] : bj[q];
+        bd[q - 1] = sw ? td : bd[q - 1]; bj[q - 1] = sw ? tj : bj[q - 1];
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(BVH_THREADS) void k_normals_knn(const BvhViewT<3> bv, int n, int tree_depth, float vpx, float vpy, float vpz,
+                                                             float* __restrict__ nrm_out /* AoS n x 3 */, float* __restrict__ curv_out) {
+    extern __shared__ unsigned short bvh_lb16[];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * BVH_THREADS + tid;
+    if (i >= n) return;
+    const float px = bv.tgt.c[0][i], py = bv.tgt.c[1][i], pz = bv.tgt.c[2][i];
+    float nx = NAN, ny = NAN, nz = NAN, curv = NAN;
+    if (finite3(px, py, pz) && bv.n_valid >= 3) {
+        float bd[K]; int bj[K];
+#pragma unroll
+        for (int q = 0; q < K; q++) { bd[q] = FLT_MAX; bj[q] = 0x7fffffff; }
+        f2 p2[3] = {{px, px}, {py, py}, {pz, pz}};
+        TravState st; st.depth = 0; st.idx = 0; st.pending = 0u; st.alive = true;
+        while (st.alive) {
+            while (st.alive && st.depth < tree_depth) {
+                const f2 l = pair_lb<3>(bv.nodes + ((1 << st.depth) - 1 + st.idx), p2);
+                const bool swap = l.y < l.x;
+                const float ln = swap ? l.y : l.x, lf = swap ? l.x : l.y;
+                const float worst = bd[K - 1];
+                const bool take_near = !(ln * 0.99999f > worst), take_far = !(lf * 0.99999f > worst);
+                if (take_near) {
+                    if (take_far) { bvh_lb16[st.depth * BVH_THREADS + tid] = (unsigned short)(__float_as_uint(lf) >> 16); st.pending |= 1u << st.depth; }
+                    st.idx = 2 * st.idx + (swap ? 1 : 0); st.depth++;
+                } else st.alive = false;
+                trav_pop(st, bvh_lb16, tid, BVH_THREADS, bd[K - 1]);
+            }
+            if (st.alive) {
+                const BvhLeafT<3>* __restrict__ lf = bv.leaves + st.idx;
+#pragma unroll
+                for (int t = 0; t < BVH_LEAF; t++) {
+                    const float dx = px - lf->c[0][t], dy = py - lf->c[1][t], dz = pz - lf->c[2][t];
+                    const float d = (dx * dx + dy * dy) + dz * dz;
+                    const int j = lf->idx[t];
+                    if (j >= 0 && ((d < bd[K - 1]) | ((d == bd[K - 1]) & (j < bj[K - 1])))) knn_insert<K>(bd, bj, d, j);
+                }
+                st.alive = false;
+                trav_pop(st, bvh_lb16, tid, BVH_THREADS, bd[K - 1]);
+            }
+        }
+        int cnt = 0;
+        double m[3] = {0, 0, 0}, cxx = 0, cxy = 0, cxz = 0, cyy = 0, cyz = 0, czz = 0;
+#pragma unroll
+        for (int q = 0; q < K; q++) if (bd[q] < FLT_MAX) { const int j = bj[q]; m[0] += bv.tgt.c[0][j]; m[1] += bv.tgt.c[1][j]; m[2] += bv.tgt.c[2][j]; cnt++; }
+        if (cnt >= 3) {
+            m[0] /= cnt; m[1] /= cnt; m[2] /= cnt;
+#pragma unroll
+            for (int q = 0; q < K; q++) if (bd[q] < FLT_MAX) {
+                const int j = bj[q];
+                const double a = bv.tgt.c[0][j] - m[0], b = bv.tgt.c[1][j] - m[1], c = bv.tgt.c[2][j] - m[2];
+                cxx += a * a; cxy += a * b; cxz += a * c; cyy += b * b; cyz += b * c; czz += c * c;
+            }
+            double A[9] = {cxx / cnt, cxy / cnt, cxz / cnt, cxy / cnt, cyy / cnt, cyz / cnt, cxz / cnt, cyz / cnt, czz / cnt}, V[9], ev[3];
+            jacobi_eig_sym<3>(A, V, ev);
+            int s0 = 0; if (ev[1] < ev[s0]) s0 = 1; if (ev[2] < ev[s0]) s0 = 2;
+            double vx = V[0 * 3 + s0], vy = V[1 * 3 + s0], vz = V[2 * 3 + s0];
+            const double len = sqrt(vx * vx + vy * vy + vz * vz);
+            vx /= len; vy /= len; vz /= len;
+            if ((vpx - px) * vx + (vpy - py) * vy + (vpz - pz) * vz < 0) { vx = -vx; vy = -vy; vz = -vz; }   // flipNormalTowardsViewpoint
+            nx = (float)vx; ny = (float)vy; nz = (float)vz;
+            const double tr = ev[0] + ev[1] + ev[2];
+            curv = tr > 0 ? (float)(fabs(ev[s0]) / tr) : 0.f;
+        }
+    }
+    nrm_out[(size_t)i * 3] = nx; nrm_out[(size_t)i * 3 + 1] = ny; nrm_out[(size_t)i * 3 + 2] = nz;
+    if (curv_out) curv_out[i] = curv;
+}
+
 __global__ void k_iota(int* p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = i; }
 
 // Morton key of the (untransformed) query points -> spatially coherent waves for k_knn_bvh.
@@ -603,6 +693,35 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double* lds /* [4]
     }
 }
 
+// Same contract for MANY accumulators (the 34 sums of k_post): a full shuffle tree would be 6 x 2 x NV LDS-crossbar permutes
+// per wave.  Here two shuffle steps fold 64 lanes to 16, those 16 partials go through LDS transposed ([wave][value][16+1]),
+// and thread a < NV adds the 4 x 16 partials of value a in a fixed order.  lds: 4 * NV * 17 doubles.  Result: thread a holds
+// the block total of accumulator a (a < NV); returned through `out`.
+template <int NV>
+__device__ __forceinline__ double block_reduce_wide(double (&v)[NV], double* lds) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NV; a++) {
+        double x = v[a];
+        x += __shfl_down(x, 32, WAVE);
+        x += __shfl_down(x, 16, WAVE);
+        if (lane < 16) lds[(w * NV + a) * 17 + lane] = x;
+    }
+    __syncthreads();
+    double tot = 0.0;
+    if (threadIdx.x < NV) {
+#pragma unroll
+        for (int ww = 0; ww < 4; ww++) {
+            const double* row = lds + (ww * NV + threadIdx.x) * 17;
+            double part = 0.0;
+#pragma unroll
+            for (int l = 0; l < 16; l++) part += row[l];
+            tot += part;
+        }
+    }
+    return tot;
+}
+
 // Rows of the reference's 4n x 6 system in fp32, then their contribution to J^T J (upper triangle,
 // 21) and J^T r (6) in fp64.  kind 0: point-to-plane (ICPOptimizer.h:698-750); kind 1: symmetric
 // (ICPOptimizer.h:806-852, s/d already centred, n = n_t + n_s).
@@ -655,7 +774,7 @@ struct PostParams {
 
 // One fused pass over the correspondences (weight, reject, filter, accumulate).
 __global__ __launch_bounds__(POST_THREADS) void k_post(const PostParams pp) {
-    __shared__ double lds[4 * 34];
+    __shared__ double lds[4 * 34 * 17];
     double acc[34];
 #pragma unroll
     for (int a = 0; a < 34; a++) acc[a] = 0.0;
@@ -724,18 +843,14 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(const PostParams pp) {
             acc[SUM_M + 13] += (double)d2 * ws0; acc[SUM_M + 14] += (double)d2 * ws1; acc[SUM_M + 15] += (double)d2 * ws2;
         }
     }
-    block_reduce<34>(acc, lds);
-    if (threadIdx.x == 0) {
-        double* o = pp.partials + (size_t)blockIdx.x * NSUM;
-#pragma unroll
-        for (int a = 0; a < 34; a++) o[a] = acc[a];
-    }
+    const double tot = block_reduce_wide<34>(acc, lds);
+    if (threadIdx.x < 34) pp.partials[(size_t)blockIdx.x * NSUM + threadIdx.x] = tot;
 }
 
 // Second pass of the symmetric objective: rows need the means of the valid pairs first
 // (ICPOptimizer.h:797-809).  Reads the final matches written by k_post.
 __global__ __launch_bounds__(POST_THREADS) void k_sym_accumulate(const PostParams pp) {
-    __shared__ double lds[4 * 27];
+    __shared__ double lds[4 * 27 * 17];
     double acc[27];
 #pragma unroll
     for (int a = 0; a < 27; a++) acc[a] = 0.0;
@@ -756,12 +871,8 @@ __global__ __launch_bounds__(POST_THREADS) void k_sym_accumulate(const PostParam
         const float n0 = pp.tnx[j] + ns0, n1 = pp.tny[j] + ns1, n2 = pp.tnz[j] + ns2;    // :809
         accumulate_rows(1, s0 - ms0, s1 - ms1, s2 - ms2, d0 - md0, d1 - md1, d2 - md2, n0, n1, n2, m.weight, acc);
     }
-    block_reduce<27>(acc, lds);
-    if (threadIdx.x == 0) {
-        double* o = pp.partials + (size_t)blockIdx.x * NSUM + SUM_M;
-#pragma unroll
-        for (int a = 0; a < 27; a++) o[a] = acc[a];
-    }
+    const double tot = block_reduce_wide<27>(acc, lds);
+    if (threadIdx.x < 27) pp.partials[(size_t)blockIdx.x * NSUM + SUM_M + threadIdx.x] = tot;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -61,6 +61,7 @@ struct icp_ctx {
     bool owns_stream = false;
     icp_params prm;
     Cloud tgt, src, qry;                 // qry: scratch cloud of icp_query_matches
+    Cloud nrm_cloud; Bvh nrm_bvh;        // scratch of icp_estimate_normals
     Bvh bvh, bvh6;                       // exact kd-ordered BVH of the target over xyz / over xyz+rgb (knn_backend == ICP_KNN_LBVH)
     std::vector<uint8_t> src_valid;      // host mask: finite point && finite normal (PointCloud.h:334)
     float src_lo[3] = {0, 0, 0}, src_hi[3] = {0, 0, 0};   // bounding box of the finite source points
@@ -457,7 +458,8 @@ int icp_ctx_destroy(icp_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release(c->tgt); release(c->src); release(c->qry); release(c->conv_src); release(c->conv_ref);
-    for (Bvh* b : {&c->bvh6}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
+    release(c->nrm_cloud);
+    for (Bvh* b : {&c->bvh6, &c->nrm_bvh}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
     release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->order_full); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) { release(kv.second.idx); release(kv.second.order); }
     release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->sums);
@@ -806,6 +808,38 @@ int icp_backproject_depth(icp_ctx* c, const float* depth, const uint8_t* rgbx, f
     HIPCK(c, hipMemcpyAsync(normals_out, d_nrm, n * 12, hipMemcpyDeviceToHost, c->stream));
     if (rgbx && rgba_out) HIPCK(c, hipMemcpyAsync(rgba_out, d_rgba, n * 4, hipMemcpyDeviceToHost, c->stream));
     if (valid_out) HIPCK(c, hipMemcpyAsync(valid_out, d_valid, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return ICP_OK;
+}
+
+int icp_estimate_normals(icp_ctx* c, const float* xyz, int32_t n, int32_t k, const float viewpoint[3], float* normals_out, float* curvature_out) {
+    if (!c || !xyz || !normals_out || n <= 0 || k < 3 || k > 8) { if (c) c->err = "icp_estimate_normals: bad argument (k must be 3..8)"; return ICP_ERR_INVALID_ARG; }
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    Cloud& cl = c->nrm_cloud; Bvh& b = c->nrm_bvh;
+    if ((rc = upload_cloud(c, cl, xyz, nullptr, nullptr, n, false))) return rc;
+    b.valid = false; b.finite_idx.clear(); b.finite_idx.reserve((size_t)n);
+    for (int i = 0; i < n; i++) { const float* q = xyz + (size_t)i * 3; if (std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2])) b.finite_idx.push_back(i); }
+    b.n_valid = (int)b.finite_idx.size();
+    CoordPtrs<3> cp; cp.c[0] = cl.x.as<float>(); cp.c[1] = cl.y.as<float>(); cp.c[2] = cl.z.as<float>();
+    if ((rc = build_bvh<3>(c, b, cp))) return rc;
+    BvhViewT<3> bv; bv.leaves = b.leaves.as<BvhLeafT<3>>(); bv.nodes = b.nodes.as<BvhNodeT<3>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
+    int depth = 0; while ((1 << depth) < b.Lp) depth++;
+    if ((rc = ensure(c, c->staging, (size_t)n * 16))) return rc;
+    float* d_n = c->staging.as<float>(); float* d_c = d_n + (size_t)n * 3;
+    const float vx = viewpoint ? viewpoint[0] : 0.f, vy = viewpoint ? viewpoint[1] : 0.f, vz = viewpoint ? viewpoint[2] : 0.f;
+    const dim3 grid((n + BVH_THREADS - 1) / BVH_THREADS), block(BVH_THREADS); const size_t lds = (size_t)(depth + 1) * BVH_THREADS * 2;
+    switch (k) {
+        case 3: hipLaunchKernelGGL(k_normals_knn<3>, grid, block, lds, c->stream, bv, n, depth, vx, vy, vz, d_n, d_c); break;
+        case 4: hipLaunchKernelGGL(k_normals_knn<4>, grid, block, lds, c->stream, bv, n, depth, vx, vy, vz, d_n, d_c); break;
+        case 5: hipLaunchKernelGGL(k_normals_knn<5>, grid, block, lds, c->stream, bv, n, depth, vx, vy, vz, d_n, d_c); break;
+        case 6: hipLaunchKernelGGL(k_normals_knn<6>, grid, block, lds, c->stream, bv, n, depth, vx, vy, vz, d_n, d_c); break;
+        case 7: hipLaunchKernelGGL(k_normals_knn<7>, grid, block, lds, c->stream, bv, n, depth, vx, vy, vz, d_n, d_c); break;
+        default: hipLaunchKernelGGL(k_normals_knn<8>, grid, block, lds, c->stream, bv, n, depth, vx, vy, vz, d_n, d_c); break;
+    }
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(normals_out, d_n, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream));
+    if (curvature_out) HIPCK(c, hipMemcpyAsync(curvature_out, d_c, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return ICP_OK;
 }

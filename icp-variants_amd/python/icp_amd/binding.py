@@ -50,7 +50,7 @@ class IcpTiming(C.Structure):
 EXPORTS = ["icp_ctx_create", "icp_ctx_create_on_stream", "icp_ctx_destroy", "icp_last_error", "icp_params_default",
            "icp_set_params", "icp_get_params", "icp_set_target", "icp_set_source", "icp_query_matches", "icp_match",
            "icp_correspond", "icp_iterate", "icp_run", "icp_get_timing", "icp_set_convergence_reference", "icp_rmse", "icp_benchmark_error",
-           "icp_transform_points", "icp_transform_normals", "icp_version", "icp_schedule", "icp_select_hash", "icp_backproject_depth"]
+           "icp_transform_points", "icp_transform_normals", "icp_version", "icp_schedule", "icp_select_hash", "icp_backproject_depth", "icp_estimate_normals"]
 
 _lib = None
 
@@ -214,6 +214,13 @@ class Context:
                                                 _ptr(E), C.c_int32(w), C.c_int32(h), C.c_float(max_distance), C.c_int32(int(fix_color_index)),
                                                 _ptr(xyz), _ptr(nrm), _ptr(rgba), _ptr(valid)))
         return xyz, nrm, rgba, valid.astype(bool)
+
+    def estimate_normals(self, xyz, k=5, viewpoint=(0.0, 0.0, 0.0)):
+        """PointCloud(pcl cloud): k-NN PCA normals flipped towards the viewpoint (PointCloud.h:41-76)."""
+        x = _f32(xyz); vp = np.asarray(viewpoint, np.float32)
+        nrm = np.empty_like(x); curv = np.empty(len(x), np.float32)
+        self._ck(self.lib.icp_estimate_normals(self.h, _ptr(x), C.c_int32(len(x)), C.c_int32(k), _ptr(vp), _ptr(nrm), _ptr(curv)))
+        return nrm, curv
 
     def transform_points(self, xyz, pose):
         x = _f32(xyz); out = np.empty_like(x)

@@ -159,6 +159,12 @@ int icp_backproject_depth(icp_ctx* ctx, const float* depth, const uint8_t* rgbx,
                           const float extrinsics[16], int32_t width, int32_t height, float max_distance, int32_t fix_color_index,
                           float* xyz_out, float* normals_out, uint8_t* rgba_out, uint8_t* valid_out);
 
+/* PointCloud(pcl::PointCloud<PointXYZ>::Ptr) (PointCloud.h:41-76): normals of an unorganised scan from its k nearest
+ * neighbours (pcl::NormalEstimation, setKSearch(5), viewpoint (0,0,0)): exact k-NN on the device, fp64 PCA, normal flipped
+ * towards the viewpoint.  k in {3..8}.  Non-finite points get NaN normals.  curvature_out may be NULL.  Uses scratch
+ * buffers of the context only (target / source stay untouched). */
+int icp_estimate_normals(icp_ctx* ctx, const float* xyz, int32_t n, int32_t k, const float viewpoint[3], float* normals_out, float* curvature_out);
+
 /* The selection predicate of RANDOM_SAMPLING: point `index` is kept in resample number `iteration` iff the returned
  * 32-bit hash is < proba * 2^32.  Exposed so host code (and the test oracle) can reproduce the device's choice exactly. */
 uint32_t icp_select_hash(uint32_t seed, uint32_t iteration, uint32_t index);

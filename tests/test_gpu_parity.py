@@ -414,3 +414,41 @@ def test_backproject_depth_bit_exact(gpu_ctx_factory, orc):
         assert np.array_equal(g[1].view(np.uint32), o[1].view(np.uint32))
         assert np.array_equal(g[2], o[2]) and np.array_equal(g[3], o[3])
     assert 0.7 < g[3].mean() < 1.0
+
+
+def test_estimate_normals_k5(gpu_ctx_factory):
+    """PointCloud(pcl cloud) normals (PointCloud.h:41-76: k = 5 PCA, flipped towards the viewpoint).  PCL is absent -> parity
+    unpinned; checked against an independent numpy/scipy restatement and against the analytic normals of the synthetic room."""
+    from scipy.spatial import cKDTree
+    from icp_amd import synth
+    pts, nrm_true, _ = synth.laser_scan(synth.scan_pose(0), 7, n_tilt=60, n_beam=200, sigma=0.0)
+    pts = pts.copy(); pts[17] = np.nan
+    c = gpu_ctx_factory()
+    sensor = synth.scan_pose(0)[:3, 3].astype(f32)
+    nrm, curv = c.estimate_normals(pts, 5, sensor)
+    ok = np.isfinite(pts).all(1)
+    assert np.isnan(nrm[17]).all() and np.isfinite(nrm[ok]).all()
+    assert np.allclose(np.linalg.norm(nrm[ok], axis=1), 1, atol=1e-5)
+    # independent restatement on a subsample: exact 5-NN (self included) -> covariance -> smallest eigenvector -> flip
+    P = pts[ok].astype(np.float64); tree = cKDTree(P)
+    sub = np.random.default_rng(0).choice(len(P), 2000, replace=False)
+    dd, ii = tree.query(P[sub], k=6)
+    idx_ok = np.nonzero(ok)[0]
+    agree = 0; checked = 0
+    for row, (q, nb, dist) in enumerate(zip(sub, ii, dd)):
+        if dist[5] - dist[4] < 1e-6:                     # ambiguous 5th neighbour (grid-like scan patterns): skip
+            continue
+        X = P[nb[:5]]; C = np.cov(X.T, bias=True); w, V = np.linalg.eigh(C)
+        if w[1] - w[0] < 1e-3 * max(w[2], 1e-30):        # degenerate neighbourhood (collinear beams): direction not unique
+            continue
+        v = V[:, 0]
+        if (sensor - P[q]) @ v < 0: v = -v
+        checked += 1
+        agree += float(np.abs(nrm[idx_ok[q]] - v).max() < 1e-4)
+        assert abs(curv[idx_ok[q]] - w[0] / w.sum()) < 1e-5
+    assert checked > 500 and agree / checked > 0.995
+    # and they are the surface normals of the (noise-free) planar scene almost everywhere
+    cosang = np.abs((nrm[ok] * nrm_true[ok]).sum(1))
+    assert np.median(cosang) > 0.9999 and (cosang > 0.99).mean() > 0.9
+    # normals point towards the sensor
+    assert (((sensor - pts[ok]) * nrm[ok]).sum(1) >= -1e-6).all()
