@@ -89,13 +89,21 @@ def batch_mode(args, world, rank, local_rank):
     scans = {}
     for p in mine:
         scans[p] = synth.eth_like_pair(p % 44, n_tilt=args.n_tilt, n_beam=args.n_beam)
-    opt = binding.LinearICPOptimizer(local_rank)
-    opt.setMatchingMethod(0); opt.setMatchingMaxDistance(10.0); opt.setMetric(1); opt.setNbOfIterations(args.iterations)
-    opt.setKnnBackend(1 if args.knn == "lbvh" else 0)
-    ctx = opt.ctx; ctx.push_params()
+    # Two contexts (= two HIP streams) per rank, driven by two host threads: while one pair iterates, the next pair's
+    # host->device upload, AoS->SoA conversion and BVH build run on the other stream (ctypes releases the GIL).
+    from concurrent.futures import ThreadPoolExecutor
+    n_ctx = 2
+    ctxs = []
+    for _ in range(n_ctx):
+        opt = binding.LinearICPOptimizer(local_rank)
+        opt.setMatchingMethod(0); opt.setMatchingMaxDistance(10.0); opt.setMetric(1); opt.setNbOfIterations(args.iterations)
+        opt.setKnnBackend(1 if args.knn == "lbvh" else 0)
+        opt.ctx.push_params()
+        ctxs.append(opt.ctx)
     eye = binding.pose_to_c(np.eye(4, dtype=np.float32))
+    pools = [ThreadPoolExecutor(1) for _ in range(n_ctx)]          # one worker per context: a context is single-threaded
 
-    def solve(p):
+    def solve_on(ctx, p):
         d = scans[p]
         ctx.set_target(d["tgt_pts"], d["tgt_nrm"], None)
         ctx.set_source(d["src_pts"], d["src_nrm"], None)
@@ -103,7 +111,8 @@ def batch_mode(args, world, rank, local_rank):
         return pose
 
     def step():
-        return batch.align_batch(args.pairs, solve, device="cuda")
+        futs = {p: pools[i % n_ctx].submit(solve_on, ctxs[i % n_ctx], p) for i, p in enumerate(mine)}
+        return batch.align_batch(args.pairs, lambda p: futs[p].result(), device="cuda")
 
     for _ in range(args.warmup):
         step()
