@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--n-tilt", type=int, default=344)
     ap.add_argument("--n-beam", type=int, default=1077)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-incremental", action="store_true", help="always walk the BVH (disable the exact verify-and-skip of converged queries)")
     ap.add_argument("--cpu-baseline-detail", action="store_true", help="add the SURVEY 8d CPU variants (takes ~30 s more)")
     ap.add_argument("--pairs", type=int, default=0, help="batch mode (configs[3]): align this many consecutive scan pairs per step, "
                     "sharded pair p -> rank p mod N, uploads and index builds INSIDE the timed region, one pose gather per step")
@@ -190,6 +191,7 @@ def main():
     opt.setWeightingMethod(0); opt.setRejectionMethod(1)
     opt.setKnnBackend(1 if args.knn == "lbvh" else 0)
     ctx = opt.ctx
+    ctx.params.knn_incremental = 0 if args.no_incremental else 1
     ctx.push_params()
     ctx.set_target(pair["tgt_pts"], pair["tgt_nrm"], None)              # resident in HBM before the timed region
     ctx.set_source(pair["src_pts"], pair["src_nrm"], None)
@@ -257,7 +259,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[1]: synthetic ETH-Apartment-like pair (rank, rank+1), %d x %d pts, exact %s k-NN, "
                                "point-to-plane linear, maxDist^2=10, %d iterations/step, rejection on" % (n_src, n_tgt, args.knn, args.iterations),
-                   "pairs_per_step": world, "iterations_per_step": args.iterations, "knn_backend": args.knn},
+                   "pairs_per_step": world, "iterations_per_step": args.iterations, "knn_backend": args.knn,
+                   "knn_incremental": (not args.no_incremental) and args.knn == "lbvh"},
         "correspondences_per_s": value * n_src,
         "ms_per_iteration": elapsed / (args.steps * args.iterations) * 1e3,
         "stage_ms_per_iteration": {"match": acc["match_ms"] / launches, "weight_reject_build": acc["weight_reject_build_ms"] / launches,

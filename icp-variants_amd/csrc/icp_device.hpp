@@ -121,6 +121,8 @@ struct KnnParams {
     int nseg;
     int* nn_raw;                                             // [n] raw nearest index of this launch (BVH backend), seed of the next one
     int use_prev;                                            // 1: nn_raw holds the previous iteration's result for the same queries
+    float4* qstate;                                          // [n] (query xyz when last searched or verified, lower bound on the distance to every OTHER target)
+    int incremental;                                         // 1: verify-and-skip with qstate (needs use_prev)
 };
 
 template <int DIM>
@@ -387,8 +389,9 @@ __device__ __forceinline__ f2 pair_lb(const BvhNodeT<DIM>* __restrict__ nd, cons
 }
 
 // Evaluate the 8 points of a leaf against the lane's query; exact lexicographic (d2, lowest index) update.
+// best2 follows the smallest distance among all evaluated points OTHER than the current winner (see k_knn_bvh).
 template <int DIM>
-__device__ __forceinline__ void leaf_eval(const BvhLeafT<DIM>* __restrict__ lf, const f2* p2, float& best, int& bi) {
+__device__ __forceinline__ void leaf_eval(const BvhLeafT<DIM>* __restrict__ lf, const f2* p2, float& best, int& bi, float& best2) {
     float dd[BVH_LEAF];
     float m = FLT_MAX;
 #pragma unroll
@@ -404,14 +407,16 @@ __device__ __forceinline__ void leaf_eval(const BvhLeafT<DIM>* __restrict__ lf, 
         dd[t] = d.x; dd[t + 1] = d.y;
         m = fminf(fminf(m, d.x), d.y);
     }
-    if (m <= best) {                     // something in this leaf ties or beats the running best
+    if (m <= best) {                     // something in this leaf ties or beats the running best (or IS the running best)
 #pragma unroll
         for (int t = 0; t < BVH_LEAF; t++) {
             const int j = lf->idx[t];
             const bool take = (dd[t] < best) | ((dd[t] == best) & (j < bi));     // first minimum = lowest original index
+            const float other = take ? best : ((j != bi) ? dd[t] : FLT_MAX);      // the dethroned winner, or a non-winning point
+            best2 = fminf(best2, other);
             best = take ? dd[t] : best; bi = take ? j : bi;
         }
-    }
+    } else best2 = fminf(best2, m);      // nobody here can win: all 8 are "others"
 }
 
 // Temporal seeding: ICP moves the queries a little per iteration, so the previous iteration's neighbour j0 is a
@@ -435,36 +440,40 @@ __device__ __forceinline__ void seed_from_previous(const int* __restrict__ nn_ra
 // leaves room for the full 32 waves per CU.
 struct TravState { int depth; int idx; unsigned int pending; bool alive; };
 
-__device__ __forceinline__ void trav_pop(TravState& st, const unsigned short* __restrict__ lb16, int tid, int nthreads, float best) {
+__device__ __forceinline__ void trav_pop(TravState& st, const unsigned short* __restrict__ lb16, int tid, int nthreads, float best, float& minlb) {
     while (!st.alive && st.pending) {                     // deepest pending sibling that survives the (possibly improved) bound
         const int d = 31 - __clz((int)st.pending);
         st.pending &= ~(1u << d);
         const float lb = __uint_as_float((unsigned int)lb16[d * nthreads + tid] << 16);      // <= true bound
         if (!(lb * 0.99999f > best)) { st.idx = (st.idx >> (st.depth - d - 1)) ^ 1; st.depth = d + 1; st.alive = true; }
+        else minlb = fminf(minlb, lb);                    // skipped subtree: everything in it is at least this far
     }
 }
 
 // "Near child first" traversal to completion, "while-while" shape: busy lanes first descend through internal nodes,
 // then evaluate their leaves together.
+// best2 / minlb: smallest evaluated distance of a non-winner and smallest lower bound of a skipped subtree -- together a
+// lower bound on the squared distance from the query to every target other than the winner (for the incremental search).
 template <int DIM>
 __device__ __forceinline__ void trav_run(const BvhViewT<DIM>& bv, int tree_depth, const f2* p2, TravState& st,
-                                         float& best, int& bi, unsigned short* __restrict__ lb16, int tid, int nthreads) {
+                                         float& best, int& bi, float& best2, float& minlb, unsigned short* __restrict__ lb16, int tid, int nthreads) {
     while (st.alive) {
         while (st.alive && st.depth < tree_depth) {
             const f2 l = pair_lb<DIM>(bv.nodes + ((1 << st.depth) - 1 + st.idx), p2);
             const bool swap = l.y < l.x;                  // child 1 is nearer
             const float ln = swap ? l.y : l.x, lf = swap ? l.x : l.y;
             const bool take_near = !(ln * 0.99999f > best), take_far = !(lf * 0.99999f > best);
+            minlb = fminf(minlb, take_near ? (take_far ? FLT_MAX : lf) : ln);     // whatever is skipped right here
             if (take_near) {
                 if (take_far) { lb16[st.depth * nthreads + tid] = (unsigned short)(__float_as_uint(lf) >> 16); st.pending |= 1u << st.depth; }
                 st.idx = 2 * st.idx + (swap ? 1 : 0); st.depth++;
             } else st.alive = false;                      // both children pruned (lf >= ln)
-            trav_pop(st, lb16, tid, nthreads, best);
+            trav_pop(st, lb16, tid, nthreads, best, minlb);
         }
         if (st.alive) {
-            leaf_eval<DIM>(bv.leaves + st.idx, p2, best, bi);
+            leaf_eval<DIM>(bv.leaves + st.idx, p2, best, bi, best2);
             st.alive = false;
-            trav_pop(st, lb16, tid, nthreads, best);
+            trav_pop(st, lb16, tid, nthreads, best, minlb);
         }
     }
 }
@@ -480,7 +489,8 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nb) {
 // Every lane walks the tree on its own for its own query.  Measured on MI355X (370k x 370k, DIM 3): ~26 node records and
 // ~3 leaves per query, ~50 % of the wave time waiting on dependent loads, ~33 % of the lanes active on average (traversal
 // lengths differ per lane).  What moved it: Morton-sorted queries + XCD-contiguous slices (L2 hit 59 % -> 89 %), the
-// 2-byte-per-level stack (occupancy), temporal seeding.  Tried and rejected (slower, see git history): wave-packet
+// 2-byte-per-level stack (occupancy), temporal seeding, and -- once ICP has converged -- the verify-and-skip test below,
+// which retires whole waves without a traversal.  Tried and rejected (slower, see git history): wave-packet
 // traversal with scalar node loads (the union of 64 lanes' subtrees is 3x larger), persistent lanes with wave-level
 // refill (fewer waves in flight), a second cooperative pass for queries over a step budget.
 template <int DIM>
@@ -496,14 +506,33 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, con
     if (!kp.pretransformed) { float a, b, c; xform_point(kp.ps->pose, p[0], p[1], p[2], a, b, c); p[0] = a; p[1] = b; p[2] = c; }
     if (DIM == 6) { p[3 % DIM] = kp.scr[i]; p[4 % DIM] = kp.scg[i]; p[5 % DIM] = kp.scb[i]; }
     float best = FLT_MAX; int bi = -1;
+    float lb_others = 0.f;               // lower bound on the (real) distance from p to every target except bi
     if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
         seed_from_previous<DIM>(kp.nn_raw, kp.use_prev, bv.tgt, k, p, best, bi);
-        f2 p2[DIM];
+        // Incremental search.  The last full search left, for this query, a lower bound L on the distance to every target
+        // other than its neighbour j0.  The query has since moved by delta, so every other target is still at least
+        // L - delta away (triangle inequality); if the re-evaluated distance to j0 is strictly below that, j0 is still THE
+        // unique fp32 argmin and the traversal is skipped.  All margins (1e-6 relative) dominate the fp32 rounding of the
+        // distance formula (< 4e-7), so the result is bit-identical to a full search; otherwise a full search runs.
+        bool verified = false;
+        if (kp.incremental && kp.use_prev && bi >= 0) {
+            const float4 s = kp.qstate[k];
+            const float ex = p[0] - s.x, ey = p[1] - s.y, ez = p[2] - s.z;
+            const float delta = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.000001f + 1e-30f;
+            const float lbn = (s.w - delta) * 0.999999f;
+            if (sqrtf(best) * 1.000001f < lbn) { verified = true; lb_others = lbn; }
+        }
+        if (!verified) {
+            f2 p2[DIM];
 #pragma unroll
-        for (int q = 0; q < DIM; q++) { p2[q].x = p[q]; p2[q].y = p[q]; }
-        TravState st; st.depth = 0; st.idx = 0; st.pending = 0u; st.alive = true;
-        trav_run<DIM>(bv, tree_depth, p2, st, best, bi, bvh_lb16, tid, BVH_THREADS);
+            for (int q = 0; q < DIM; q++) { p2[q].x = p[q]; p2[q].y = p[q]; }
+            float best2 = FLT_MAX, minlb = FLT_MAX;
+            TravState st; st.depth = 0; st.idx = 0; st.pending = 0u; st.alive = true;
+            trav_run<DIM>(bv, tree_depth, p2, st, best, bi, best2, minlb, bvh_lb16, tid, BVH_THREADS);
+            lb_others = sqrtf(fminf(best2, minlb)) * 0.999999f;
+        }
     }
+    if (kp.qstate) { float4 s; s.x = p[0]; s.y = p[1]; s.z = p[2]; s.w = lb_others; kp.qstate[k] = s; }
     if (kp.nn_raw) kp.nn_raw[k] = bi;
     icp_match_t m;
     if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
@@ -547,6 +576,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_normals_knn(const BvhViewT<3> b
         for (int q = 0; q < K; q++) { bd[q] = FLT_MAX; bj[q] = 0x7fffffff; }
         f2 p2[3] = {{px, px}, {py, py}, {pz, pz}};
         TravState st; st.depth = 0; st.idx = 0; st.pending = 0u; st.alive = true;
+        float unused_minlb = FLT_MAX;
         while (st.alive) {
             while (st.alive && st.depth < tree_depth) {
                 const f2 l = pair_lb<3>(bv.nodes + ((1 << st.depth) - 1 + st.idx), p2);
@@ -558,7 +588,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_normals_knn(const BvhViewT<3> b
                     if (take_far) { bvh_lb16[st.depth * BVH_THREADS + tid] = (unsigned short)(__float_as_uint(lf) >> 16); st.pending |= 1u << st.depth; }
                     st.idx = 2 * st.idx + (swap ? 1 : 0); st.depth++;
                 } else st.alive = false;
-                trav_pop(st, bvh_lb16, tid, BVH_THREADS, bd[K - 1]);
+                trav_pop(st, bvh_lb16, tid, BVH_THREADS, bd[K - 1], unused_minlb);
             }
             if (st.alive) {
                 const BvhLeafT<3>* __restrict__ lf = bv.leaves + st.idx;
@@ -570,7 +600,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_normals_knn(const BvhViewT<3> b
                     if (j >= 0 && ((d < bd[K - 1]) | ((d == bd[K - 1]) & (j < bj[K - 1])))) knn_insert<K>(bd, bj, d, j);
                 }
                 st.alive = false;
-                trav_pop(st, bvh_lb16, tid, BVH_THREADS, bd[K - 1]);
+                trav_pop(st, bvh_lb16, tid, BVH_THREADS, bd[K - 1], unused_minlb);
             }
         }
         int cnt = 0;

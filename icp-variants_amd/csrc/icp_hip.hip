@@ -68,6 +68,7 @@ struct icp_ctx {
     DevBuf order_full, okeys, okeys2, ovals, otemp; bool order_full_valid = false;   // Morton order of the full source
     std::map<int, Level> levels;         // multires selections by decimation factor
     DevBuf sel_lists, sel_counts, sel_blocks;            // RANDOM_SAMPLING: per-iteration index lists, their sizes, scan scratch
+    DevBuf qstate;                                       // incremental k-NN: per-query position + bound on the other targets
     DevBuf ps, matches, d2, best64, nn_raw, partials, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
     Cloud conv_src, conv_ref; int conv_n = 0;
     float cos_reject = 0.5f;
@@ -300,11 +301,15 @@ int launch_match(icp_ctx* c, const QuerySet& q) {
     kp.tx = c->tgt.x.as<float>(); kp.ty = c->tgt.y.as<float>(); kp.tz = c->tgt.z.as<float>();
     kp.tcr = c->tgt.cr.as<float>(); kp.tcg = c->tgt.cg.as<float>(); kp.tcb = c->tgt.cb.as<float>();
     kp.mpad = c->tgt.npad; kp.ps = c->ps.as<PoseState>(); kp.pretransformed = q.pretransformed; kp.max_dist = p.max_distance;
-    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0;
+    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0; kp.qstate = nullptr; kp.incremental = 0;
     if (p.knn_backend == ICP_KNN_LBVH) {
         kp.nseg = 1;
         if ((rc = ensure(c, c->nn_raw, (size_t)q.n * 4))) return rc;
         kp.nn_raw = c->nn_raw.as<int>(); kp.use_prev = q.seed_prev ? 1 : 0;
+        if (p.knn_incremental && !q.pretransformed) {
+            if ((rc = ensure(c, c->qstate, (size_t)q.n * 16))) return rc;
+            kp.qstate = c->qstate.as<float4>(); kp.incremental = 1;
+        }
         if (q.use_colors) return launch_bvh_query<6>(c, c->bvh6, target_coords6(c), kp, q.order, q.n);
         return launch_bvh_query<3>(c, c->bvh, target_coords3(c), kp, q.order, q.n);
     }
@@ -424,6 +429,7 @@ int icp_params_default(icp_params* p) {
     p->metric = 0; p->matching = 0; p->weighting = 0; p->rejection = 1; p->color_icp = 0; p->multires = 0;   // ICPOptimizer.h:29-31
     p->n_iterations = 20; p->max_distance = 0.0003f;
     p->knn_backend = ICP_KNN_BRUTE_FORCE; p->record_rmse = 0;
+    p->knn_incremental = 1;
     p->selection = 0; p->selection_proba = 1.0f; p->selection_seed = 0u;      // setSelectionMethod(SELECT_ALL), proba default 1.0 (ICPOptimizer.h:58)
     return ICP_OK;
 }
@@ -462,7 +468,7 @@ int icp_ctx_destroy(icp_ctx* c) {
     for (Bvh* b : {&c->bvh6, &c->nrm_bvh}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
     release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->order_full); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) { release(kv.second.idx); release(kv.second.order); }
-    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->sums);
+    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);

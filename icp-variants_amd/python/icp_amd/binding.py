@@ -33,7 +33,8 @@ class IcpParams(C.Structure):
                 ("color_icp", C.c_int32), ("multires", C.c_int32), ("n_iterations", C.c_int32), ("max_distance", C.c_float),
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
                 ("width", C.c_int32), ("height", C.c_int32), ("knn_backend", C.c_int32),
-                ("selection", C.c_int32), ("selection_proba", C.c_float), ("selection_seed", C.c_uint32), ("record_rmse", C.c_int32)]
+                ("selection", C.c_int32), ("selection_proba", C.c_float), ("selection_seed", C.c_uint32),
+                ("knn_incremental", C.c_int32), ("record_rmse", C.c_int32)]
 
 
 class IcpIterStats(C.Structure):

@@ -68,6 +68,8 @@ typedef struct icp_params {
     float   selection_proba; /* Bernoulli probability per point and per iteration (selection.h:88-106)                     */
     uint32_t selection_seed; /* the reference seeds std::mt19937 from random_device (selection.h:76-79: not reproducible);
                                 here a counter-based hash of (seed, iteration, point index) decides -- see icp_select_hash */
+    int32_t knn_incremental; /* 1 (default): BVH k-NN verifies the previous neighbour with an exact distance bound and skips the
+                                tree walk when it provably cannot change (bit-identical results); 0: always walk the tree */
     int32_t record_rmse;     /* bit 0: per-iteration RMSE against the convergence reference (ConvergenceMeasure.h:50-66);
                                 bit 1: also the benchmark error (m_runBenchmark, ConvergenceMeasure.h:74-78,104-151) */
 } icp_params;

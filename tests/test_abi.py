@@ -47,7 +47,7 @@ def test_params_default_match_reference_ctor():
 
 def test_struct_layouts():
     from icp_amd import binding
-    assert ctypes.sizeof(binding.IcpParams) == 19 * 4
+    assert ctypes.sizeof(binding.IcpParams) == 20 * 4
     assert ctypes.sizeof(binding.IcpIterStats) == 4 + 4 + 64 + 4 + 4 + 4
     assert binding.MATCH_DTYPE.itemsize == 8            # struct Match, NearestNeighbor.h:7-10
 

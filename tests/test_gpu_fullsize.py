@@ -113,3 +113,19 @@ def test_fullsize_colour_knn_tum_geometry(gpu_ctx_factory, orc):
     assert [x["n_src"] for x in recs][0] < 300 and recs[-1]["n_src"] > 250000          # coarse-to-fine schedule ran
     ang, tr = pose_error(pose, r["gt"])
     assert ang < 2e-3 and tr < 5e-3
+
+
+def test_fullsize_incremental_search_bit_identical(gpu_ctx_factory, eth_pair):
+    """50 iterations at 370k with and without the verify-and-skip k-NN: identical poses, bit for bit, every iteration;
+    and the converged iterations really are cheaper."""
+    res = []
+    for inc in (1, 0):
+        c = gpu_ctx_factory()
+        c.params.max_distance = 10.0; c.params.metric = 1; c.params.n_iterations = 50; c.params.knn_backend = 1; c.params.knn_incremental = inc
+        c.push_params(); c.set_target(eth_pair["tgt_pts"], eth_pair["tgt_nrm"]); c.set_source(eth_pair["src_pts"], eth_pair["src_nrm"])
+        c.run(np.eye(4))
+        pose, recs, _ = c.run(np.eye(4))
+        res.append((recs, c.timing()["match_ms"]))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert a["n_valid"] == b["n_valid"] and np.array_equal(a["pose"], b["pose"])
+    assert res[0][1] < res[1][1]

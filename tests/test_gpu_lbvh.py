@@ -131,3 +131,36 @@ def test_lbvh6_colour_multires_run_equals_brute(gpu_ctx_factory):
         pose, recs, _ = c.run(np.eye(4))
         res.append((pose, [x["n_valid"] for x in recs]))
     assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+
+
+@pytest.mark.parametrize("case", ["bunny_p2p_multires", "dups_p2plane", "colour6d", "eth_mid_symmetric"])
+def test_incremental_search_is_bit_identical_to_full_search(gpu_ctx_factory, bunny, case):
+    """knn_incremental (verify the previous neighbour with an exact bound, skip the tree walk when it cannot change) must not
+    change a single match: every iteration's pose and valid count equal the always-walk run bit for bit."""
+    from icp_amd import synth
+    kw = dict(max_distance=0.0003, metric=1, n_iterations=30)
+    if case == "bunny_p2p_multires":
+        tgt = (bunny["tgt_pts"], bunny["tgt_nrm"], None); src = (bunny["src_pts"], bunny["src_nrm"], None); kw.update(metric=0, multires=1)
+    elif case == "dups_p2plane":
+        tp = np.concatenate([bunny["tgt_pts"], bunny["tgt_pts"][::3]]); tn = np.concatenate([bunny["tgt_nrm"], bunny["tgt_nrm"][::3]])   # exact duplicates: ties everywhere
+        tgt = (tp, tn, None); src = (bunny["src_pts"], bunny["src_nrm"], None)
+    elif case == "colour6d":
+        K = np.array([[131.25, 0, 79.5], [0, 131.25, 59.5], [0, 0, 1]], f32)
+        r = synth.rgbd_pair(0, width=160, height=120, K=K)
+        tgt = synth.compact_valid(r["tgt_pts"], r["tgt_nrm"], r["tgt_rgba"]); src = synth.compact_valid(r["src_pts"], r["src_nrm"], r["src_rgba"])
+        kw.update(max_distance=0.1, color_icp=1, weighting=3)
+    else:
+        p = synth.eth_like_pair(2, n_tilt=86, n_beam=270)
+        tgt = (p["tgt_pts"], p["tgt_nrm"], None); src = (p["src_pts"], p["src_nrm"], None); kw.update(max_distance=10.0, metric=2, n_iterations=40)
+    out = []
+    for inc in (1, 0):
+        c = gpu_ctx_factory()
+        for k, v in kw.items():
+            setattr(c.params, k, v)
+        c.params.knn_backend = LBVH; c.params.knn_incremental = inc; c.push_params()
+        c.set_target(*tgt); c.set_source(*src)
+        pose, recs, _ = c.run(np.eye(4))
+        out.append(recs)
+    assert len(out[0]) == len(out[1])
+    for a, b in zip(*out):
+        assert a["n_valid"] == b["n_valid"] and np.array_equal(a["pose"], b["pose"])
