@@ -123,6 +123,7 @@ struct KnnParams {
     int use_prev;                                            // 1: nn_raw holds the previous iteration's result for the same queries
     float4* qstate;                                          // [n] (query xyz when last searched or verified, lower bound on the distance to every OTHER target)
     int incremental;                                         // 1: verify-and-skip with qstate (needs use_prev)
+    int* work_items; int* work_n;                            // two-pass incremental search: queries that failed verification (list, count)
 };
 
 template <int DIM>
@@ -228,11 +229,18 @@ template <> struct BvhLeafT<3> { float c[3][BVH_LEAF]; int idx[BVH_LEAF]; };
 typedef BvhNodeT<3> BvhNode;
 typedef BvhLeafT<3> BvhLeaf;
 
+// 4-wide node of the same tree with two binary levels collapsed: the boxes of the four grandchildren, SoA per axis (two
+// packed-f32 pairs each).  96 B / 192 B.  Half the dependent loads per query of the binary walk -- the search is bound by
+// the latency of that chain, not by bytes or flops.
+template <int DIM> struct BvhQuadT { float lo[DIM][4]; float hi[DIM][4]; };
+
 template <int DIM> struct CoordPtrs { const float* c[DIM]; };
 
 template <int DIM> struct BvhViewT {
     const BvhLeafT<DIM>* leaves;  // [max(n_leaves,1)] kd-ordered points, 8 per leaf; pads are +inf with index -1
     const BvhNodeT<DIM>* nodes;   // [Lp - 1] internal nodes in heap order (node k: children 2k+1, 2k+2; leaves start at Lp-1)
+    const BvhQuadT<DIM>* qnodes;  // [(4^Lq - 1) / 3] 4-wide nodes, level l at offset (4^l - 1) / 3; the children of level Lq - 1 are the leaves
+    int Lq;                       // 4-wide levels = ceil(log2(Lp) / 2)  (an odd binary depth gets a virtual root with one empty half)
     int n_valid;                  // finite target points in the tree
     int Lp;                       // leaves rounded up to a power of two
     CoordPtrs<DIM> tgt;           // target planes by original index (seeding)
@@ -372,6 +380,30 @@ __global__ void k_bvh_nodes(const BvhLeafT<DIM>* __restrict__ leaves, int n_leav
     for (int k = 0; k < DIM; k++) { out->lo[k][0] = lo0[k]; out->lo[k][1] = lo1[k]; out->hi[k][0] = hi0[k]; out->hi[k][1] = hi1[k]; }
 }
 
+// 4-wide nodes from the finished binary records.  Virtual binary depth v = real depth + pad (pad = 1 when the real depth of
+// the leaves is odd: a virtual root whose second half is empty); 4-wide node (l, idx) is virtual node (2l, idx) and stores the
+// boxes of the virtual nodes (2l + 2, 4 idx + c), each of which is a child box of a real binary record one level up.
+template <int DIM>
+__global__ void k_bvh_quad_nodes(const BvhNodeT<DIM>* __restrict__ nodes, int pad, int Lq, BvhQuadT<DIM>* __restrict__ qnodes) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = (int)((((1ll << (2 * Lq)) - 1) / 3) * 4);
+    if (t >= total) return;
+    const int q = t >> 2, c = t & 3;
+    int l = 0; while ((int)(((1ll << (2 * (l + 1))) - 1) / 3) <= q) l++;         // level of 4-wide node q
+    const int idx = q - (int)(((1ll << (2 * l)) - 1) / 3);
+    const int rd = 2 * l + 2 - pad, ri = 4 * idx + c;                          // real depth / index of child c
+    float lo[DIM], hi[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }      // empty box: lower bound = +inf
+    if (ri < (1 << rd)) {
+        const BvhNodeT<DIM>* nd = nodes + ((1 << (rd - 1)) - 1 + (ri >> 1));
+#pragma unroll
+        for (int k = 0; k < DIM; k++) { lo[k] = nd->lo[k][ri & 1]; hi[k] = nd->hi[k][ri & 1]; }
+    }
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { qnodes[q].lo[k][c] = lo[k]; qnodes[q].hi[k][c] = hi[k]; }
+}
+
 // Lower bounds of the fp32 squared distance from the query to any point of the two child boxes, both at once (packed
 // f32), accumulated in the SAME order as the point distance: ((e0^2 + e1^2) + e2^2) [+ e3^2 + e4^2 + e5^2].
 template <int DIM>
@@ -478,6 +510,79 @@ __device__ __forceinline__ void trav_run(const BvhViewT<DIM>& bv, int tree_depth
     }
 }
 
+// ---- 4-wide walk -------------------------------------------------------------------------------------------------------
+// Same exactness argument as the binary walk (a box is skipped only if its lower bound, computed with the operation order
+// of the point distance, exceeds the running best), half the depth.  Per-lane state: level, index within the level and
+// 4 pending-child bits per level in one 64-bit mask; the pending children's bounds live in LDS as 4 x 16-bit truncated
+// floats per level and lane (one 8-byte access).  Siblings are visited in ascending order of their bound.
+struct QuadState { int L; int idx; unsigned long long pending; bool alive; };
+
+template <int DIM>
+__device__ __forceinline__ void quad_lb(const BvhQuadT<DIM>* __restrict__ nd, const f2* p2, f2& l01, f2& l23) {
+#pragma unroll
+    for (int k = 0; k < DIM; k++) {
+        const f2 lo0 = *(const f2*)&nd->lo[k][0], lo1 = *(const f2*)&nd->lo[k][2], hi0 = *(const f2*)&nd->hi[k][0], hi1 = *(const f2*)&nd->hi[k][2];
+        const f2 a0 = lo0 - p2[k], b0 = p2[k] - hi0, a1 = lo1 - p2[k], b1 = p2[k] - hi1;
+        const f2 e0 = {fmaxf(fmaxf(a0.x, b0.x), 0.f), fmaxf(fmaxf(a0.y, b0.y), 0.f)};
+        const f2 e1 = {fmaxf(fmaxf(a1.x, b1.x), 0.f), fmaxf(fmaxf(a1.y, b1.y), 0.f)};
+        const f2 s0 = e0 * e0, s1 = e1 * e1;
+        l01 = (k == 0) ? s0 : l01 + s0;
+        l23 = (k == 0) ? s1 : l23 + s1;
+    }
+}
+
+__device__ __forceinline__ void quad_pop(QuadState& st, const uint2* __restrict__ lbq, int tid, int nthreads, float best, float& minlb) {
+    while (!st.alive && st.pending) {
+        const int lv = (63 - __clzll((long long)st.pending)) >> 2;                // deepest level with pending children
+        const unsigned int bits = (unsigned int)(st.pending >> (4 * lv)) & 0xFu;
+        const uint2 w = lbq[lv * nthreads + tid];
+        const float l0 = (bits & 1u) ? __uint_as_float(w.x << 16) : FLT_MAX, l1 = (bits & 2u) ? __uint_as_float(w.x & 0xFFFF0000u) : FLT_MAX;
+        const float l2 = (bits & 4u) ? __uint_as_float(w.y << 16) : FLT_MAX, l3 = (bits & 8u) ? __uint_as_float(w.y & 0xFFFF0000u) : FLT_MAX;
+        const float m = fminf(fminf(l0, l1), fminf(l2, l3));                      // truncated bounds: <= the true ones
+        if (m * 0.99999f > best) {                                               // the nearest pending sibling is out: so are the others
+            minlb = fminf(minlb, m);
+            st.pending &= ~(0xFull << (4 * lv));
+        } else {
+            const int c = (l0 == m) ? 0 : (l1 == m) ? 1 : (l2 == m) ? 2 : 3;
+            st.pending &= ~(1ull << (4 * lv + c));
+            st.idx = ((st.idx >> (2 * (st.L - lv))) << 2) | c; st.L = lv + 1; st.alive = true;
+        }
+    }
+}
+
+template <int DIM>
+__device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const f2* p2, QuadState& st,
+                                         float& best, int& bi, float& best2, float& minlb, uint2* __restrict__ lbq, int tid, int nthreads) {
+    const int Lq = bv.Lq;
+    while (st.alive) {
+        while (st.alive && st.L < Lq) {
+            f2 l01, l23;
+            quad_lb<DIM>(bv.qnodes + ((0x5555555555555555ull & ((1ull << (2 * st.L)) - 1ull)) + (unsigned long long)st.idx), p2, l01, l23);
+            const float m = fminf(fminf(l01.x, l01.y), fminf(l23.x, l23.y));
+            const bool s0 = !(l01.x * 0.99999f > best), s1 = !(l01.y * 0.99999f > best), s2 = !(l23.x * 0.99999f > best), s3 = !(l23.y * 0.99999f > best);
+            minlb = fminf(minlb, fminf(fminf(s0 ? FLT_MAX : l01.x, s1 ? FLT_MAX : l01.y), fminf(s2 ? FLT_MAX : l23.x, s3 ? FLT_MAX : l23.y)));   // skipped right here
+            if (!(m * 0.99999f > best)) {
+                const int c = (l01.x == m) ? 0 : (l01.y == m) ? 1 : (l23.x == m) ? 2 : 3;
+                const unsigned int pend = ((s0 ? 1u : 0u) | (s1 ? 2u : 0u) | (s2 ? 4u : 0u) | (s3 ? 8u : 0u)) & ~(1u << c);
+                if (pend) {
+                    uint2 w;
+                    w.x = (__float_as_uint(l01.x) >> 16) | (__float_as_uint(l01.y) & 0xFFFF0000u);
+                    w.y = (__float_as_uint(l23.x) >> 16) | (__float_as_uint(l23.y) & 0xFFFF0000u);
+                    lbq[st.L * nthreads + tid] = w;
+                    st.pending |= (unsigned long long)pend << (4 * st.L);
+                }
+                st.idx = (st.idx << 2) | c; st.L++;
+            } else st.alive = false;                      // all four children pruned
+            quad_pop(st, lbq, tid, nthreads, best, minlb);
+        }
+        if (st.alive) {
+            leaf_eval<DIM>(bv.leaves + st.idx, p2, best, bi, best2);
+            st.alive = false;
+            quad_pop(st, lbq, tid, nthreads, best, minlb);
+        }
+    }
+}
+
 // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (block b runs on the XCD group b % 8), each
 // with a private 4 MiB L2.  With Morton-sorted queries, giving every XCD group ONE contiguous slice of the sorted list
 // means its L2 only has to hold the part of the tree under that slice (plus the shared top levels) instead of all of it.
@@ -494,50 +599,120 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nb) {
 // traversal with scalar node loads (the union of 64 lanes' subtrees is 3x larger), persistent lanes with wave-level
 // refill (fewer waves in flight), a second cooperative pass for queries over a step budget.
 template <int DIM>
-__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, int tree_depth) {
-    extern __shared__ unsigned short bvh_lb16[];          // [tree_depth + 1][BVH_THREADS]
-    const int tid = threadIdx.x;
-    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS + tid;
-    if (t >= kp.n) return;
-    const int k = qorder ? qorder[t] : t;                 // spatially sorted queries: neighbouring lanes walk similar paths
+__device__ __forceinline__ void knn_load_query(const KnnParams& kp, int k, float* p) {
     const int i = kp.sel ? kp.sel[k] : k;
-    float p[DIM];
     p[0] = kp.sx[i]; p[1] = kp.sy[i]; p[2] = kp.sz[i];
     if (!kp.pretransformed) { float a, b, c; xform_point(kp.ps->pose, p[0], p[1], p[2], a, b, c); p[0] = a; p[1] = b; p[2] = c; }
     if (DIM == 6) { p[3 % DIM] = kp.scr[i]; p[4 % DIM] = kp.scg[i]; p[5 % DIM] = kp.scb[i]; }
-    float best = FLT_MAX; int bi = -1;
+}
+
+// Incremental search.  The last full search left, for this query, a lower bound L on the distance to every target
+// other than its neighbour j0.  The query has since moved by delta, so every other target is still at least
+// L - delta away (triangle inequality); if the re-evaluated distance to j0 is strictly below that, j0 is still THE
+// unique fp32 argmin and the traversal is skipped.  All margins (1e-6 relative) dominate the fp32 rounding of the
+// distance formula (< 4e-7), so the result is bit-identical to a full search; otherwise a full search runs.
+// Seeds (best, bi) with the previous neighbour either way.
+template <int DIM>
+__device__ __forceinline__ bool knn_try_verify(const KnnParams& kp, const BvhViewT<DIM>& bv, int k, const float* p, float& best, int& bi, float& lb_others) {
+    seed_from_previous<DIM>(kp.nn_raw, kp.use_prev, bv.tgt, k, p, best, bi);
+    if (kp.incremental && kp.use_prev && bi >= 0) {
+        const float4 s = kp.qstate[k];
+        const float ex = p[0] - s.x, ey = p[1] - s.y, ez = p[2] - s.z;
+        const float delta = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.000001f + 1e-30f;
+        const float lbn = (s.w - delta) * 0.999999f;
+        if (sqrtf(best) * 1.000001f < lbn) { lb_others = lbn; return true; }
+    }
+    return false;
+}
+
+template <int DIM>
+__device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, const float* p, float best, int bi, float lb_others) {
+    if (kp.qstate) { float4 s; s.x = p[0]; s.y = p[1]; s.z = p[2]; s.w = lb_others; kp.qstate[k] = s; }
+    if (kp.nn_raw) kp.nn_raw[k] = bi;
+    if (kp.d2_out) kp.d2_out[k] = best;
+}
+
+template <int DIM>
+__device__ __forceinline__ void knn_bvh_query(const KnnParams& kp, const BvhViewT<DIM>& bv, int k, uint2* __restrict__ lbq, int tid,
+                                              float& best, int& bi) {
+    float p[DIM];
+    knn_load_query<DIM>(kp, k, p);
+    best = FLT_MAX; bi = -1;
     float lb_others = 0.f;               // lower bound on the (real) distance from p to every target except bi
     if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
-        seed_from_previous<DIM>(kp.nn_raw, kp.use_prev, bv.tgt, k, p, best, bi);
-        // Incremental search.  The last full search left, for this query, a lower bound L on the distance to every target
-        // other than its neighbour j0.  The query has since moved by delta, so every other target is still at least
-        // L - delta away (triangle inequality); if the re-evaluated distance to j0 is strictly below that, j0 is still THE
-        // unique fp32 argmin and the traversal is skipped.  All margins (1e-6 relative) dominate the fp32 rounding of the
-        // distance formula (< 4e-7), so the result is bit-identical to a full search; otherwise a full search runs.
-        bool verified = false;
-        if (kp.incremental && kp.use_prev && bi >= 0) {
-            const float4 s = kp.qstate[k];
-            const float ex = p[0] - s.x, ey = p[1] - s.y, ez = p[2] - s.z;
-            const float delta = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.000001f + 1e-30f;
-            const float lbn = (s.w - delta) * 0.999999f;
-            if (sqrtf(best) * 1.000001f < lbn) { verified = true; lb_others = lbn; }
-        }
-        if (!verified) {
+        if (!knn_try_verify<DIM>(kp, bv, k, p, best, bi, lb_others)) {
             f2 p2[DIM];
 #pragma unroll
             for (int q = 0; q < DIM; q++) { p2[q].x = p[q]; p2[q].y = p[q]; }
             float best2 = FLT_MAX, minlb = FLT_MAX;
-            TravState st; st.depth = 0; st.idx = 0; st.pending = 0u; st.alive = true;
-            trav_run<DIM>(bv, tree_depth, p2, st, best, bi, best2, minlb, bvh_lb16, tid, BVH_THREADS);
+            QuadState st; st.L = 0; st.idx = 0; st.pending = 0ull; st.alive = true;
+            quad_run<DIM>(bv, p2, st, best, bi, best2, minlb, lbq, tid, BVH_THREADS);
             lb_others = sqrtf(fminf(best2, minlb)) * 0.999999f;
         }
     }
-    if (kp.qstate) { float4 s; s.x = p[0]; s.y = p[1]; s.z = p[2]; s.w = lb_others; kp.qstate[k] = s; }
-    if (kp.nn_raw) kp.nn_raw[k] = bi;
+    knn_store_state<DIM>(kp, k, p, best, bi, lb_others);
+}
+
+// Which query does this lane serve?  Either position t of the (Morton-sorted) query order, or -- second pass of the
+// incremental search -- entry t of the work list, whose length is only known on the device: the launch covers the worst case
+// and blocks past the end retire at once; the XCD-contiguous slices are cut over the blocks actually in use.
+__device__ __forceinline__ int knn_bvh_lane_query(const KnnParams& kp, const int* __restrict__ qorder, int tid) {
+    if (kp.work_items) {
+        const int n = *kp.work_n, nb = (n + BVH_THREADS - 1) / BVH_THREADS;
+        if ((int)blockIdx.x >= nb) return -1;
+        const int t = xcd_contiguous_block(blockIdx.x, nb) * BVH_THREADS + tid;
+        return t < n ? kp.work_items[t] : -1;
+    }
+    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS + tid;
+    if (t >= kp.n) return -1;
+    return qorder ? qorder[t] : t;                        // spatially sorted queries: neighbouring lanes walk similar paths
+}
+
+template <int DIM>
+__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder) {
+    extern __shared__ uint2 bvh_lbq[];                    // [Lq][BVH_THREADS] pending-sibling bounds
+    const int tid = threadIdx.x;
+    const int k = knn_bvh_lane_query(kp, qorder, tid);
+    if (k < 0) return;
+    float best; int bi;
+    knn_bvh_query<DIM>(kp, bv, k, bvh_lbq, tid, best, bi);
     icp_match_t m;
     if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
     kp.out[k] = m;
-    if (kp.d2_out) kp.d2_out[k] = best;
+}
+
+// First pass of the incremental search: a streaming kernel that re-evaluates every query against its previous neighbour.
+// Verified queries are finished here; the others are appended to the work list for the tree walk (one wave-aggregated
+// atomic per wave; the list order varies from run to run, the per-query results do not depend on it).  Packing the
+// survivors densely matters: left in place they would keep almost every wave walking the tree at a few lanes' utilisation.
+constexpr int VERIFY_THREADS = 256;
+template <int DIM>
+__global__ __launch_bounds__(VERIFY_THREADS) void k_knn_verify(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder) {
+    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * VERIFY_THREADS + threadIdx.x;
+    bool push = false; int k = -1;
+    if (t < kp.n) {
+        k = qorder ? qorder[t] : t;
+        float p[DIM];
+        knn_load_query<DIM>(kp, k, p);
+        float best = FLT_MAX, lb_others = 0.f; int bi = -1;
+        if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
+            push = !knn_try_verify<DIM>(kp, bv, k, p, best, bi, lb_others);
+        }
+        if (!push) {
+            knn_store_state<DIM>(kp, k, p, best, bi, lb_others);
+            icp_match_t m;
+            if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
+            kp.out[k] = m;
+        }
+    }
+    const unsigned long long mask = __ballot(push);
+    if (mask) {
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(kp.work_n, __popcll(mask));
+        base = __shfl(base, 0, WAVE);
+        if (push) kp.work_items[base + __popcll(mask & ((1ull << lane) - 1ull))] = k;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -725,9 +900,9 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double* lds /* [4]
 
 // Same contract for MANY accumulators (the 34 sums of k_post): a full shuffle tree would be 6 x 2 x NV LDS-crossbar permutes
 // per wave.  Here two shuffle steps fold 64 lanes to 16, those 16 partials go through LDS transposed ([wave][value][16+1]),
-// and thread a < NV adds the 4 x 16 partials of value a in a fixed order.  lds: 4 * NV * 17 doubles.  Result: thread a holds
+// and thread a < NV adds the NW x 16 partials of value a in a fixed order.  lds: NW * NV * 17 doubles.  Result: thread a holds
 // the block total of accumulator a (a < NV); returned through `out`.
-template <int NV>
+template <int NV, int NW>
 __device__ __forceinline__ double block_reduce_wide(double (&v)[NV], double* lds) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
@@ -741,7 +916,7 @@ __device__ __forceinline__ double block_reduce_wide(double (&v)[NV], double* lds
     double tot = 0.0;
     if (threadIdx.x < NV) {
 #pragma unroll
-        for (int ww = 0; ww < 4; ww++) {
+        for (int ww = 0; ww < NW; ww++) {
             const double* row = lds + (ww * NV + threadIdx.x) * 17;
             double part = 0.0;
 #pragma unroll
@@ -769,23 +944,40 @@ __device__ __forceinline__ void accumulate_rows(int kind, float s0, float s1, fl
     }
     A0[3] = n0; A0[4] = n1; A0[5] = n2;
     const float f0 = 1.0f * w, f1 = 0.1f * w;             // LAMBDA_PLANE/SYMMETRIC = 1, LAMBDA_POINT = 0.1 (:737-738,:839-840)
-    float R[4][6], b[4];
+    // row 0: dense, scaled by f0 (:740-741 / :842-843)
+    double r0[6];
 #pragma unroll
-    for (int c = 0; c < 6; c++) R[0][c] = A0[c] * f0;
-    b[0] = b0 * f0;
-    R[1][0] = 0.f * f1;  R[1][1] = s2 * f1;    R[1][2] = (-s1) * f1; R[1][3] = 1.f * f1; R[1][4] = 0.f * f1; R[1][5] = 0.f * f1; b[1] = (d0 - s0) * f1;
-    R[2][0] = (-s2) * f1; R[2][1] = 0.f * f1;  R[2][2] = s0 * f1;    R[2][3] = 0.f * f1; R[2][4] = 1.f * f1; R[2][5] = 0.f * f1; b[2] = (d1 - s1) * f1;
-    R[3][0] = s1 * f1;   R[3][1] = (-s0) * f1; R[3][2] = 0.f * f1;   R[3][3] = 0.f * f1; R[3][4] = 0.f * f1; R[3][5] = 1.f * f1; b[3] = (d2 - s2) * f1;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int c = 0; c < 6; c++) r0[c] = (double)(A0[c] * f0);
+    const double rb0 = (double)(b0 * f0);
+    {
         int q = 0;
 #pragma unroll
         for (int a = 0; a < 6; a++) {
 #pragma unroll
-            for (int c = a; c < 6; c++) { acc[q] += (double)R[r][a] * (double)R[r][c]; q++; }
+            for (int c = a; c < 6; c++) { acc[q] += r0[a] * r0[c]; q++; }
         }
 #pragma unroll
-        for (int a = 0; a < 6; a++) acc[21 + a] += (double)R[r][a] * (double)b[r];
+        for (int a = 0; a < 6; a++) acc[21 + a] += r0[a] * rb0;
+    }
+    // rows 1-3: the point rows [0, s2, -s1, 1,0,0 | d0-s0], [-s2, 0, s0, 0,1,0 | d1-s1], [s1, -s0, 0, 0,0,1 | d2-s2], each scaled by
+    // f1 (:743-750 / :845-852).  Only their non-zero entries are accumulated (for finite weights the zero entries contribute
+    // +0.0 in the dense form), in the same row order, so the fp64 sums are exactly those of the dense 4n x 6 system.
+    // upper-triangle slots: (0,0)=0 (0,1)=1 (0,2)=2 (0,4)=4 (0,5)=5 (1,1)=6 (1,2)=7 (1,3)=8 (1,5)=10 (2,2)=11 (2,3)=12 (2,4)=13 (3,3)=15 (4,4)=18 (5,5)=20
+    const double g = (double)(1.f * f1);
+    {   // row 1
+        const double p1 = (double)(s2 * f1), p2 = (double)((-s1) * f1), rr = (double)((d0 - s0) * f1);
+        acc[6] += p1 * p1; acc[7] += p1 * p2; acc[8] += p1 * g; acc[11] += p2 * p2; acc[12] += p2 * g; acc[15] += g * g;
+        acc[21 + 1] += p1 * rr; acc[21 + 2] += p2 * rr; acc[21 + 3] += g * rr;
+    }
+    {   // row 2
+        const double q0 = (double)((-s2) * f1), q2 = (double)(s0 * f1), rr = (double)((d1 - s1) * f1);
+        acc[0] += q0 * q0; acc[2] += q0 * q2; acc[4] += q0 * g; acc[11] += q2 * q2; acc[13] += q2 * g; acc[18] += g * g;
+        acc[21 + 0] += q0 * rr; acc[21 + 2] += q2 * rr; acc[21 + 4] += g * rr;
+    }
+    {   // row 3
+        const double t0 = (double)(s1 * f1), t1 = (double)((-s0) * f1), rr = (double)((d2 - s2) * f1);
+        acc[0] += t0 * t0; acc[1] += t0 * t1; acc[5] += t0 * g; acc[6] += t1 * t1; acc[10] += t1 * g; acc[20] += g * g;
+        acc[21 + 0] += t0 * rr; acc[21 + 1] += t1 * rr; acc[21 + 5] += g * rr;
     }
 }
 
@@ -799,82 +991,111 @@ struct PostParams {
     icp_match_t* matches;          // in: after matching; out: after weighting + pruning
     int metric, weighting, rejection;
     float max_dist, cos_reject;  // cos_reject: largest float c with acosf(c) > 60 deg on this host's libm
-    double* partials;            // [gridDim.x][NSUM]
+    double* partials;            // [NSUM][gridDim.x]: sum a of block b at a * gridDim.x + b (the reducer reads rows contiguously)
 };
 
-// One fused pass over the correspondences (weight, reject, filter, accumulate).
+// Weight, reject, filter and accumulate ONE correspondence (source position k, match m after matching): the body of
+// applyWeights / pruneCorrespondences / the validity filter / the system build.  Writes the final Match back.
+__device__ __forceinline__ void post_point(const PostParams& pp, int k, icp_match_t m, double* acc /* 34 */) {
+    if (m.idx < 0) return;
+    const float* __restrict__ P = pp.ps->pose;
+    const float* __restrict__ N = pp.ps->nmat;
+    const int i = pp.sel ? pp.sel[k] : k;
+    float s0, s1, s2, ns0, ns1, ns2;
+    xform_point(P, pp.sx[i], pp.sy[i], pp.sz[i], s0, s1, s2);
+    xform_normal(N, pp.snx[i], pp.sny[i], pp.snz[i], ns0, ns1, ns2);
+    const int j = m.idx;
+    const float d0 = pp.tx[j], d1 = pp.ty[j], d2 = pp.tz[j];
+    const float nt0 = pp.tnx[j], nt1 = pp.tny[j], nt2 = pp.tnz[j];
+    const bool fin_sd = finite3(s0, s1, s2) && finite3(d0, d1, d2);
+    // ---- applyWeights, weighting.h:44-90 ----
+    if (pp.weighting != ICP_WEIGHT_CONSTANT) {
+        float wnew = 0.0f;
+        if (pp.weighting == ICP_WEIGHT_DISTANCES || pp.weighting == ICP_WEIGHT_COLORS) {
+            if (fin_sd) {
+                const float e0 = s0 - d0, e1 = s1 - d1, e2 = s2 - d2;
+                const float q = ((e0 * e0 + e1 * e1) + e2 * e2) / pp.max_dist;
+                wnew += (float)(1.0 - (double)q);          // weighting.h:19
+            }
+        }
+        if (pp.weighting == ICP_WEIGHT_NORMALS) {
+            if (finite3(ns0, ns1, ns2) && finite3(nt0, nt1, nt2))
+                wnew += ns0 * nt0 + (ns1 * nt1 + ns2 * nt2);   // weighting.h:24 (Eigen dot tree)
+        }
+        if (pp.weighting == ICP_WEIGHT_COLORS) {
+            const uint32_t a = pp.srgba[i], b = pp.trgba[j];
+            const int e0 = (int)(uint8_t)((a & 0xFF) - (b & 0xFF));           // weighting.h:28 uint8 wrap-around
+            const int e1 = (int)(uint8_t)(((a >> 8) & 0xFF) - ((b >> 8) & 0xFF));
+            const int e2 = (int)(uint8_t)(((a >> 16) & 0xFF) - ((b >> 16) & 0xFF));
+            const float cq = (float)(e0 * e0 + e1 * e1 + e2 * e2) / (float)195075;
+            wnew *= (float)(1.0 - (double)cq);             // weighting.h:29,86
+        }
+        m.weight = wnew;
+    }
+    // ---- pruneCorrespondences, ICPOptimizer.h:157-174 ----
+    if (pp.rejection == 1) {
+        const float dt = ns0 * nt0 + (ns1 * nt1 + ns2 * nt2);
+        const float na = sqrtf(ns0 * ns0 + (ns1 * ns1 + ns2 * ns2));
+        const float nb = sqrtf(nt0 * nt0 + (nt1 * nt1 + nt2 * nt2));
+        const float c = dt / (na * nb);
+        // acos(c) > 60deg  <=>  -1 <= c <= cos_reject ; NaN / |c| > 1 => acos is NaN => kept
+        if (c >= -1.0f && c <= pp.cos_reject) m.idx = -1;
+    }
+    pp.matches[k] = m;
+    if (m.idx < 0 || !fin_sd) return;                      // ICPOptimizer.h:596-598
+    const float w = m.weight;
+    acc[SUM_N] += 1.0;
+    acc[SUM_S] += (double)s0; acc[SUM_S + 1] += (double)s1; acc[SUM_S + 2] += (double)s2;
+    acc[SUM_D] += (double)d0; acc[SUM_D + 1] += (double)d1; acc[SUM_D + 2] += (double)d2;
+    if (pp.metric == ICP_METRIC_POINT_TO_PLANE) {
+        accumulate_rows(0, s0, s1, s2, d0, d1, d2, nt0, nt1, nt2, w, acc + SUM_M);
+    } else if (pp.metric == ICP_METRIC_POINT_TO_POINT) {
+        const double wd = (double)w;
+        acc[SUM_M] += wd;
+        const double ws0 = wd * s0, ws1 = wd * s1, ws2 = wd * s2;
+        acc[SUM_M + 1] += ws0; acc[SUM_M + 2] += ws1; acc[SUM_M + 3] += ws2;
+        acc[SUM_M + 4] += wd * d0; acc[SUM_M + 5] += wd * d1; acc[SUM_M + 6] += wd * d2;
+        acc[SUM_M + 7] += (double)d0 * ws0;  acc[SUM_M + 8] += (double)d0 * ws1;  acc[SUM_M + 9] += (double)d0 * ws2;
+        acc[SUM_M + 10] += (double)d1 * ws0; acc[SUM_M + 11] += (double)d1 * ws1; acc[SUM_M + 12] += (double)d1 * ws2;
+        acc[SUM_M + 13] += (double)d2 * ws0; acc[SUM_M + 14] += (double)d2 * ws1; acc[SUM_M + 15] += (double)d2 * ws2;
+    }
+}
+
+// One fused pass over the correspondences (weight, reject, filter, accumulate) -- used after the scan / projective matchers.
 __global__ __launch_bounds__(POST_THREADS) void k_post(const PostParams pp) {
     __shared__ double lds[4 * 34 * 17];
     double acc[34];
 #pragma unroll
     for (int a = 0; a < 34; a++) acc[a] = 0.0;
-    const float* __restrict__ P = pp.ps->pose;
-    const float* __restrict__ N = pp.ps->nmat;
-    for (int k = blockIdx.x * POST_THREADS + threadIdx.x; k < pp.n; k += gridDim.x * POST_THREADS) {
-        icp_match_t m = pp.matches[k];
-        if (m.idx < 0) continue;
-        const int i = pp.sel ? pp.sel[k] : k;
-        float s0, s1, s2, ns0, ns1, ns2;
-        xform_point(P, pp.sx[i], pp.sy[i], pp.sz[i], s0, s1, s2);
-        xform_normal(N, pp.snx[i], pp.sny[i], pp.snz[i], ns0, ns1, ns2);
-        const int j = m.idx;
-        const float d0 = pp.tx[j], d1 = pp.ty[j], d2 = pp.tz[j];
-        const float nt0 = pp.tnx[j], nt1 = pp.tny[j], nt2 = pp.tnz[j];
-        const bool fin_sd = finite3(s0, s1, s2) && finite3(d0, d1, d2);
-        // ---- applyWeights, weighting.h:44-90 ----
-        if (pp.weighting != ICP_WEIGHT_CONSTANT) {
-            float wnew = 0.0f;
-            if (pp.weighting == ICP_WEIGHT_DISTANCES || pp.weighting == ICP_WEIGHT_COLORS) {
-                if (fin_sd) {
-                    const float e0 = s0 - d0, e1 = s1 - d1, e2 = s2 - d2;
-                    const float q = ((e0 * e0 + e1 * e1) + e2 * e2) / pp.max_dist;
-                    wnew += (float)(1.0 - (double)q);          // weighting.h:19
-                }
-            }
-            if (pp.weighting == ICP_WEIGHT_NORMALS) {
-                if (finite3(ns0, ns1, ns2) && finite3(nt0, nt1, nt2))
-                    wnew += ns0 * nt0 + (ns1 * nt1 + ns2 * nt2);   // weighting.h:24 (Eigen dot tree)
-            }
-            if (pp.weighting == ICP_WEIGHT_COLORS) {
-                const uint32_t a = pp.srgba[i], b = pp.trgba[j];
-                const int e0 = (int)(uint8_t)((a & 0xFF) - (b & 0xFF));           // weighting.h:28 uint8 wrap-around
-                const int e1 = (int)(uint8_t)(((a >> 8) & 0xFF) - ((b >> 8) & 0xFF));
-                const int e2 = (int)(uint8_t)(((a >> 16) & 0xFF) - ((b >> 16) & 0xFF));
-                const float cq = (float)(e0 * e0 + e1 * e1 + e2 * e2) / (float)195075;
-                wnew *= (float)(1.0 - (double)cq);             // weighting.h:29,86
-            }
-            m.weight = wnew;
-        }
-        // ---- pruneCorrespondences, ICPOptimizer.h:157-174 ----
-        if (pp.rejection == 1) {
-            const float dt = ns0 * nt0 + (ns1 * nt1 + ns2 * nt2);
-            const float na = sqrtf(ns0 * ns0 + (ns1 * ns1 + ns2 * ns2));
-            const float nb = sqrtf(nt0 * nt0 + (nt1 * nt1 + nt2 * nt2));
-            const float c = dt / (na * nb);
-            // acos(c) > 60deg  <=>  -1 <= c <= cos_reject ; NaN / |c| > 1 => acos is NaN => kept
-            if (c >= -1.0f && c <= pp.cos_reject) m.idx = -1;
-        }
-        pp.matches[k] = m;
-        if (m.idx < 0 || !fin_sd) continue;                    // ICPOptimizer.h:596-598
-        const float w = m.weight;
-        acc[SUM_N] += 1.0;
-        acc[SUM_S] += (double)s0; acc[SUM_S + 1] += (double)s1; acc[SUM_S + 2] += (double)s2;
-        acc[SUM_D] += (double)d0; acc[SUM_D + 1] += (double)d1; acc[SUM_D + 2] += (double)d2;
-        if (pp.metric == ICP_METRIC_POINT_TO_PLANE) {
-            accumulate_rows(0, s0, s1, s2, d0, d1, d2, nt0, nt1, nt2, w, acc + SUM_M);
-        } else if (pp.metric == ICP_METRIC_POINT_TO_POINT) {
-            const double wd = (double)w;
-            acc[SUM_M] += wd;
-            const double ws0 = wd * s0, ws1 = wd * s1, ws2 = wd * s2;
-            acc[SUM_M + 1] += ws0; acc[SUM_M + 2] += ws1; acc[SUM_M + 3] += ws2;
-            acc[SUM_M + 4] += wd * d0; acc[SUM_M + 5] += wd * d1; acc[SUM_M + 6] += wd * d2;
-            acc[SUM_M + 7] += (double)d0 * ws0;  acc[SUM_M + 8] += (double)d0 * ws1;  acc[SUM_M + 9] += (double)d0 * ws2;
-            acc[SUM_M + 10] += (double)d1 * ws0; acc[SUM_M + 11] += (double)d1 * ws1; acc[SUM_M + 12] += (double)d1 * ws2;
-            acc[SUM_M + 13] += (double)d2 * ws0; acc[SUM_M + 14] += (double)d2 * ws1; acc[SUM_M + 15] += (double)d2 * ws2;
-        }
+    for (int k = blockIdx.x * POST_THREADS + threadIdx.x; k < pp.n; k += gridDim.x * POST_THREADS) post_point(pp, k, pp.matches[k], acc);
+    const double tot = block_reduce_wide<34, 4>(acc, lds);
+    if (threadIdx.x < 34) pp.partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = tot;
+}
+
+// BVH k-NN with the post stage as its epilogue: the lane that found the neighbour of query k immediately weighs / rejects /
+// accumulates it, so matches never make a round trip through memory and the gathers of the post stage overlap with other
+// waves' tree walks.  One kernel instead of two per iteration.  Block partials keep the fixed-order reduction contract.
+template <int DIM>
+__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {
+    extern __shared__ uint2 bvh_lbq[];                    // [Lq][BVH_THREADS] pending-sibling bounds; reused by the reduction
+    constexpr int NW = BVH_THREADS / WAVE;
+    const int tid = threadIdx.x;
+    const int k = knn_bvh_lane_query(kp, qorder, tid);
+    double acc[34];
+#pragma unroll
+    for (int a = 0; a < 34; a++) acc[a] = 0.0;
+    if (k >= 0) {
+        float best; int bi;
+        knn_bvh_query<DIM>(kp, bv, k, bvh_lbq, tid, best, bi);
+        icp_match_t m;
+        if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
+        if (m.idx < 0) pp.matches[k] = m; else post_point(pp, k, m, acc);
     }
-    const double tot = block_reduce_wide<34>(acc, lds);
-    if (threadIdx.x < 34) pp.partials[(size_t)blockIdx.x * NSUM + threadIdx.x] = tot;
+    __syncthreads();                                      // the traversal stacks are dead: reuse LDS for the reduction
+    double* lds = (double*)bvh_lbq;
+    const double tot = block_reduce_wide<34, NW>(acc, lds);
+    const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);                  // partial slot = logical block -> fixed summation order
+    if (tid < 34) pp.partials[(size_t)tid * gridDim.x + lb] = tot;
 }
 
 // Second pass of the symmetric objective: rows need the means of the valid pairs first
@@ -901,8 +1122,8 @@ __global__ __launch_bounds__(POST_THREADS) void k_sym_accumulate(const PostParam
         const float n0 = pp.tnx[j] + ns0, n1 = pp.tny[j] + ns1, n2 = pp.tnz[j] + ns2;    // :809
         accumulate_rows(1, s0 - ms0, s1 - ms1, s2 - ms2, d0 - md0, d1 - md1, d2 - md2, n0, n1, n2, m.weight, acc);
     }
-    const double tot = block_reduce_wide<27>(acc, lds);
-    if (threadIdx.x < 27) pp.partials[(size_t)blockIdx.x * NSUM + SUM_M + threadIdx.x] = tot;
+    const double tot = block_reduce_wide<27, 4>(acc, lds);
+    if (threadIdx.x < 27) pp.partials[(size_t)(SUM_M + threadIdx.x) * gridDim.x + blockIdx.x] = tot;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1126,7 +1347,8 @@ __device__ __host__ inline void normal_matrix_from_pose(const float* pose, float
 }
 
 struct SolveParams {
-    const double* partials; int nblocks;
+    const double* partials; int nblocks;   // [NSUM][nblocks]
+    double* totals; unsigned* ticket;      // NSUM reduced sums; arrival counter (0 between launches)
     PoseState* ps;
     int metric; int phase;         // phase 0: full solve (p2p / p2plane) or means only (symmetric); phase 1: symmetric solve
     icp_iter_stats* stats;         // record slot of this iteration (may be null)
@@ -1136,20 +1358,38 @@ struct SolveParams {
     const double* rmse_partials; int rmse_blocks;   // unused here
 };
 
-constexpr int SOLVE_THREADS = 1024;
+// Grid of NSUM blocks: block a folds the partials of sum a in a fixed order (lanes stride the producer blocks, shuffle tree,
+// then the waves in order) -- identical on every run and independent of block scheduling.  The block that finishes last (ticket
+// counter, release/acquire fences at agent scope) gathers the NSUM totals and runs the small fp64 solve + pose composition.
+constexpr int SOLVE_THREADS = 256;
 __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParams sp) {
     __shared__ double tot[NSUM];
-    // fixed-order reduction of the block partials: wave w owns sums w, w+4, ...; lanes stride the
-    // blocks sequentially, then a shuffle tree -- identical order on every run.
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int a = w; a < NSUM; a += SOLVE_THREADS / WAVE) {
+    __shared__ double wsum[SOLVE_THREADS / WAVE];
+    __shared__ int is_last;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, a = blockIdx.x;
+    {
+        const double* __restrict__ row = sp.partials + (size_t)a * sp.nblocks;
         double x = 0.0;
-        for (int b = lane; b < sp.nblocks; b += WAVE) x += sp.partials[(size_t)b * NSUM + a];
+        for (int b = threadIdx.x; b < sp.nblocks; b += SOLVE_THREADS) x += row[b];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
-        if (lane == 0) tot[a] = x;
+        if (lane == 0) wsum[w] = x;
     }
     __syncthreads();
+    if (threadIdx.x == 0) {
+        double x = wsum[0];
+        for (int k = 1; k < SOLVE_THREADS / WAVE; k++) x += wsum[k];
+        __hip_atomic_store(sp.totals + a, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const unsigned t = atomicAdd(sp.ticket, 1u);
+        is_last = (t == (unsigned)(NSUM - 1));
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (threadIdx.x < NSUM) tot[threadIdx.x] = __hip_atomic_load(sp.totals + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
     if (threadIdx.x != 0) return;
+    *sp.ticket = 0u;                                      // ready for the next launch on this stream
     if (sp.sums_out) for (int a = 0; a < NSUM; a++) sp.sums_out[a] = tot[a];
     PoseState* ps = sp.ps;
     const double n = tot[SUM_N];

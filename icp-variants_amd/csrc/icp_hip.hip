@@ -48,7 +48,8 @@ struct Level { DevBuf idx; DevBuf order; int n = 0; };   // selection (original 
 struct Bvh {
     bool valid = false;
     int n_valid = 0, n_leaves = 0, Lp = 1;
-    DevBuf keys, keys2, vals, vals2, temp, leaves, nodes, lvl, wbox;
+    DevBuf keys, keys2, vals, vals2, temp, leaves, nodes, qnodes, lvl, wbox;
+    int Lq = 0;                                       // 4-wide levels
     std::vector<int> finite_idx;                     // indices of the finite target points, increasing
     double build_ms = 0.0;
 };
@@ -59,6 +60,10 @@ struct icp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
+    bool stage_events = true;            // per-stage HIP events inside icp_run (ICP_HIP_STAGE_EVENTS=0: only whole-run events)
+    bool trace = false;                  // ICP_HIP_TRACE=1: per-iteration stage times on stderr
+    bool two_pass = false;               // incremental k-NN as verify pass + packed tree-walk pass (ICP_HIP_TWO_PASS=1; measured slower: walk latency is exposed)
+    bool fuse_post = true;               // BVH matcher runs weight / reject / accumulate as its epilogue (ICP_HIP_FUSE_POST=0 disables)
     icp_params prm;
     Cloud tgt, src, qry;                 // qry: scratch cloud of icp_query_matches
     Cloud nrm_cloud; Bvh nrm_bvh;        // scratch of icp_estimate_normals
@@ -69,7 +74,7 @@ struct icp_ctx {
     std::map<int, Level> levels;         // multires selections by decimation factor
     DevBuf sel_lists, sel_counts, sel_blocks;            // RANDOM_SAMPLING: per-iteration index lists, their sizes, scan scratch
     DevBuf qstate;                                       // incremental k-NN: per-query position + bound on the other targets
-    DevBuf ps, matches, d2, best64, nn_raw, partials, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
+    DevBuf ps, matches, d2, best64, nn_raw, work_items, work_counts, partials, totals, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
     Cloud conv_src, conv_ref; int conv_n = 0;
     float cos_reject = 0.5f;
     std::vector<hipEvent_t> events;
@@ -161,7 +166,7 @@ int write_pose(icp_ctx* c, const float pose[16]) {
     return ICP_OK;
 }
 
-struct QuerySet { const Cloud* cl; const int* sel; int n; int pretransformed; bool use_colors; bool seed_prev; const int* order; };
+struct QuerySet { const Cloud* cl; const int* sel; int n; int pretransformed; bool use_colors; bool seed_prev; const int* order; int work_slot = -1; };
 
 int ensure_match_buffers(icp_ctx* c, int n) {
     int rc;
@@ -252,6 +257,13 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
         hipLaunchKernelGGL(k_bvh_nodes<DIM>, dim3((count + 255) / 256), dim3(256), 0, c->stream, b.leaves.as<BvhLeafT<DIM>>(), b.n_leaves, b.Lp, first, count,
                            d == depth - 1 ? 1 : 0, b.nodes.as<BvhNodeT<DIM>>());
     }
+    {   // 4-wide view of the same tree (two binary levels per step) for the 1-NN walk
+        const int pad = depth & 1;
+        b.Lq = (depth + pad) / 2;
+        const long long nq = ((1ll << (2 * b.Lq)) - 1) / 3;
+        if ((rc = ensure(c, b.qnodes, (size_t)(nq > 0 ? nq : 1) * sizeof(BvhQuadT<DIM>)))) return rc;
+        if (nq > 0) hipLaunchKernelGGL(k_bvh_quad_nodes<DIM>, dim3((unsigned)((nq * 4 + 255) / 256)), dim3(256), 0, c->stream, b.nodes.as<BvhNodeT<DIM>>(), pad, b.Lq, b.qnodes.as<BvhQuadT<DIM>>());
+    }
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipEventRecord(e1, c->stream));
     HIPCK(c, hipEventSynchronize(e1));
@@ -267,21 +279,54 @@ CoordPtrs<6> target_coords6(const icp_ctx* c) {
     cp.c[3] = c->tgt.cr.as<float>(); cp.c[4] = c->tgt.cg.as<float>(); cp.c[5] = c->tgt.cb.as<float>(); return cp;
 }
 
+PostParams make_post_params(icp_ctx* c, const int* sel, int n) {
+    const icp_params& p = c->prm;
+    PostParams pp;
+    pp.sx = c->src.x.as<float>(); pp.sy = c->src.y.as<float>(); pp.sz = c->src.z.as<float>();
+    pp.snx = c->src.nx.as<float>(); pp.sny = c->src.ny.as<float>(); pp.snz = c->src.nz.as<float>();
+    pp.srgba = c->src.rgba.as<uint32_t>(); pp.sel = sel; pp.n = n;
+    pp.tx = c->tgt.x.as<float>(); pp.ty = c->tgt.y.as<float>(); pp.tz = c->tgt.z.as<float>();
+    pp.tnx = c->tgt.nx.as<float>(); pp.tny = c->tgt.ny.as<float>(); pp.tnz = c->tgt.nz.as<float>(); pp.trgba = c->tgt.rgba.as<uint32_t>();
+    pp.ps = c->ps.as<PoseState>(); pp.matches = c->matches.as<icp_match_t>();
+    pp.metric = p.metric; pp.weighting = p.weighting; pp.rejection = p.rejection;
+    pp.max_dist = p.max_distance; pp.cos_reject = c->cos_reject; pp.partials = c->partials.as<double>();
+    return pp;
+}
+
+// fuse != nullptr: run the post stage (weight / reject / accumulate) as the epilogue of the search; *fused_blocks receives the
+// number of block partials written.
 template <int DIM>
-int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnParams& kp, const int* order, int n) {
+int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnParams& kp, const int* order, int n, bool fuse, int* fused_blocks) {
     int rc;
     if (!b.valid && (rc = build_bvh<DIM>(c, b, cp))) return rc;
     BvhViewT<DIM> bv; bv.leaves = b.leaves.as<BvhLeafT<DIM>>(); bv.nodes = b.nodes.as<BvhNodeT<DIM>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
-    int depth = 0; while ((1 << depth) < b.Lp) depth++;              // internal levels 0 .. depth-1, leaves at depth
-    hipLaunchKernelGGL(k_knn_bvh<DIM>, dim3((n + BVH_THREADS - 1) / BVH_THREADS), dim3(BVH_THREADS), (size_t)(depth + 1) * BVH_THREADS * 2, c->stream, kp, bv, order, depth);
+    bv.qnodes = b.qnodes.as<BvhQuadT<DIM>>(); bv.Lq = b.Lq;
+    const int nb = (n + BVH_THREADS - 1) / BVH_THREADS;
+    const size_t stack_bytes = (size_t)(b.Lq > 0 ? b.Lq : 1) * BVH_THREADS * 8;
+    if (kp.work_items) {
+        // incremental search in two passes: verify everything (streaming), then walk the tree for the densely packed rest
+        KnnParams first = kp;
+        hipLaunchKernelGGL(k_knn_verify<DIM>, dim3((n + VERIFY_THREADS - 1) / VERIFY_THREADS), dim3(VERIFY_THREADS), 0, c->stream, first, bv, order);
+        hipLaunchKernelGGL(k_knn_bvh<DIM>, dim3(nb), dim3(BVH_THREADS), stack_bytes, c->stream, kp, bv, (const int*)nullptr);
+    } else if (fuse) {
+        if ((rc = ensure(c, c->partials, (size_t)(nb > POST_BLOCKS ? nb : POST_BLOCKS) * NSUM * 8))) return rc;
+        const PostParams pp = make_post_params(c, kp.sel, n);
+        const size_t red_bytes = (size_t)(BVH_THREADS / WAVE) * 34 * 17 * 8;      // the reduction reuses the (dead) traversal stacks
+        hipLaunchKernelGGL(k_knn_bvh_post<DIM>, dim3(nb), dim3(BVH_THREADS), stack_bytes > red_bytes ? stack_bytes : red_bytes, c->stream, kp, bv, order, pp);
+        *fused_blocks = nb;
+    } else {
+        hipLaunchKernelGGL(k_knn_bvh<DIM>, dim3(nb), dim3(BVH_THREADS), stack_bytes, c->stream, kp, bv, order);
+    }
     HIPCK(c, hipGetLastError());
     return ICP_OK;
 }
 
-// Enqueue the matching stage (no sync).
-int launch_match(icp_ctx* c, const QuerySet& q) {
+// Enqueue the matching stage (no sync).  fused_blocks != nullptr allows the BVH matcher to run the post stage as its epilogue;
+// it is set to the number of block partials written, or left 0 when the matcher in use does not fuse.
+int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr) {
     const icp_params& p = c->prm;
     int rc;
+    if (fused_blocks) *fused_blocks = 0;
     if ((rc = ensure_match_buffers(c, q.n))) return rc;
     if (p.matching == ICP_MATCH_PROJECTIVE) {
         ProjParams pp;
@@ -310,8 +355,14 @@ int launch_match(icp_ctx* c, const QuerySet& q) {
             if ((rc = ensure(c, c->qstate, (size_t)q.n * 16))) return rc;
             kp.qstate = c->qstate.as<float4>(); kp.incremental = 1;
         }
-        if (q.use_colors) return launch_bvh_query<6>(c, c->bvh6, target_coords6(c), kp, q.order, q.n);
-        return launch_bvh_query<3>(c, c->bvh, target_coords3(c), kp, q.order, q.n);
+        kp.work_items = nullptr; kp.work_n = nullptr;
+        if (kp.incremental && kp.use_prev && q.work_slot >= 0 && c->two_pass) {
+            if ((rc = ensure(c, c->work_items, (size_t)q.n * 4))) return rc;
+            kp.work_items = c->work_items.as<int>(); kp.work_n = c->work_counts.as<int>() + q.work_slot;
+        }
+        const bool fuse = fused_blocks != nullptr && p.metric != ICP_METRIC_SYMMETRIC && !q.pretransformed && q.cl == &c->src;
+        if (q.use_colors) return launch_bvh_query<6>(c, c->bvh6, target_coords6(c), kp, q.order, q.n, fuse, fused_blocks);
+        return launch_bvh_query<3>(c, c->bvh, target_coords3(c), kp, q.order, q.n, fuse, fused_blocks);
     }
     const int bx = (q.n + WAVE - 1) / WAVE;
     const int nch = kp.mpad / KNN_CH;
@@ -335,35 +386,33 @@ int launch_match(icp_ctx* c, const QuerySet& q) {
 
 // Enqueue weight + reject + accumulate (+ symmetric second pass) + reduce/solve (no sync).
 int launch_post_and_solve(icp_ctx* c, const int* sel, int n, icp_iter_stats* d_stats, double* d_sums_out, int update_pose,
-                          hipEvent_t ev_after_post) {
+                          hipEvent_t ev_after_post, int fused_blocks = 0) {
     const icp_params& p = c->prm;
     int rc;
-    if ((rc = ensure(c, c->partials, (size_t)POST_BLOCKS * NSUM * 8))) return rc;
-    PostParams pp;
-    pp.sx = c->src.x.as<float>(); pp.sy = c->src.y.as<float>(); pp.sz = c->src.z.as<float>();
-    pp.snx = c->src.nx.as<float>(); pp.sny = c->src.ny.as<float>(); pp.snz = c->src.nz.as<float>();
-    pp.srgba = c->src.rgba.as<uint32_t>(); pp.sel = sel; pp.n = n;
-    pp.tx = c->tgt.x.as<float>(); pp.ty = c->tgt.y.as<float>(); pp.tz = c->tgt.z.as<float>();
-    pp.tnx = c->tgt.nx.as<float>(); pp.tny = c->tgt.ny.as<float>(); pp.tnz = c->tgt.nz.as<float>(); pp.trgba = c->tgt.rgba.as<uint32_t>();
-    pp.ps = c->ps.as<PoseState>(); pp.matches = c->matches.as<icp_match_t>();
-    pp.metric = p.metric; pp.weighting = p.weighting; pp.rejection = p.rejection;
-    pp.max_dist = p.max_distance; pp.cos_reject = c->cos_reject; pp.partials = c->partials.as<double>();
+    if (!fused_blocks && (rc = ensure(c, c->partials, (size_t)POST_BLOCKS * NSUM * 8))) return rc;
+    if (!c->totals.p) {                                     // NSUM totals + the arrival counter of the reduce/solve kernel
+        if ((rc = ensure(c, c->totals, NSUM * 8 + 8))) return rc;
+        HIPCK(c, hipMemsetAsync(c->totals.p, 0, NSUM * 8 + 8, c->stream));
+    }
+    const PostParams pp = make_post_params(c, sel, n);
     int nb = (n + POST_THREADS - 1) / POST_THREADS; if (nb > POST_BLOCKS) nb = POST_BLOCKS; if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(k_post, dim3(nb), dim3(POST_THREADS), 0, c->stream, pp);
+    if (fused_blocks) nb = fused_blocks;                    // the matcher already wrote the block partials
+    else hipLaunchKernelGGL(k_post, dim3(nb), dim3(POST_THREADS), 0, c->stream, pp);
     SolveParams sp; memset(&sp, 0, sizeof(sp));
     sp.partials = c->partials.as<double>(); sp.nblocks = nb; sp.ps = c->ps.as<PoseState>(); sp.metric = p.metric;
+    sp.totals = c->totals.as<double>(); sp.ticket = (unsigned*)(c->totals.as<double>() + NSUM);
     sp.n_src = n; sp.update_pose = update_pose;
     if (p.metric == ICP_METRIC_SYMMETRIC) {
         sp.phase = 0; sp.stats = nullptr; sp.sums_out = nullptr;
-        hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(SOLVE_THREADS), 0, c->stream, sp);       // means
+        hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM), dim3(SOLVE_THREADS), 0, c->stream, sp);       // means
         hipLaunchKernelGGL(k_sym_accumulate, dim3(nb), dim3(POST_THREADS), 0, c->stream, pp);
         if (ev_after_post) HIPCK(c, hipEventRecord(ev_after_post, c->stream));
         sp.phase = 1; sp.stats = d_stats; sp.sums_out = d_sums_out;
-        hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(SOLVE_THREADS), 0, c->stream, sp);
+        hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM), dim3(SOLVE_THREADS), 0, c->stream, sp);
     } else {
         if (ev_after_post) HIPCK(c, hipEventRecord(ev_after_post, c->stream));
         sp.phase = 0; sp.stats = d_stats; sp.sums_out = d_sums_out;
-        hipLaunchKernelGGL(k_reduce_solve, dim3(1), dim3(SOLVE_THREADS), 0, c->stream, sp);
+        hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM), dim3(SOLVE_THREADS), 0, c->stream, sp);
     }
     HIPCK(c, hipGetLastError());
     return ICP_OK;
@@ -445,6 +494,10 @@ int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out) {
     icp_params_default(&c->prm);
     memset(&c->timing, 0, sizeof(c->timing));
     if (hipSetDevice(device) != hipSuccess) { delete c; return ICP_ERR_HIP; }
+    { const char* e = getenv("ICP_HIP_FUSE_POST"); if (e && e[0] == '0') c->fuse_post = false; }
+    { const char* e = getenv("ICP_HIP_TRACE"); if (e && e[0] == '1') c->trace = true; }
+    { const char* e = getenv("ICP_HIP_TWO_PASS"); if (e && e[0] == '1') c->two_pass = true; }
+    { const char* e = getenv("ICP_HIP_STAGE_EVENTS"); if (e && e[0] == '0') c->stage_events = false; }
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->owns_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ICP_ERR_HIP; }
@@ -465,10 +518,11 @@ int icp_ctx_destroy(icp_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release(c->tgt); release(c->src); release(c->qry); release(c->conv_src); release(c->conv_ref);
     release(c->nrm_cloud);
+    for (Bvh* b : {&c->bvh, &c->bvh6, &c->nrm_bvh}) { release(b->qnodes); }
     for (Bvh* b : {&c->bvh6, &c->nrm_bvh}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
     release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->order_full); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) { release(kv.second.idx); release(kv.second.order); }
-    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->sums);
+    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->work_items); release(c->work_counts); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -666,6 +720,11 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     const bool rmse = (p.record_rmse & 1) && c->conv_n > 0;
     const bool fontana = (p.record_rmse & 2) && c->conv_n > 0;
     if (rmse) { if ((rc = ensure(c, c->rmse_partials, 256 * 2 * 8))) return rc; }
+    const bool ev = c->stage_events;
+    if (p.knn_backend == ICP_KNN_LBVH && p.matching == ICP_MATCH_KNN && p.knn_incremental) {     // work-list counters, one per iteration
+        if ((rc = ensure(c, c->work_counts, (size_t)iters * 4))) return rc;
+        HIPCK(c, hipMemsetAsync(c->work_counts.p, 0, (size_t)iters * 4, c->stream));
+    }
     HIPCK(c, hipEventRecord(c->events[0], c->stream));
     for (int i = 0; i < iters; i++) {
         icp_iter_stats* d_st = c->stats.as<icp_iter_stats>() + i;
@@ -673,10 +732,12 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
             // seed the search with the previous iteration's neighbours when it matched the same queries (same level)
             const bool seed = i > 0 && factors[i] == factors[i - 1] && ns[i - 1] > 0 && p.selection == 0;
             QuerySet q{&c->src, sels[i], ns[i], 0, p.color_icp != 0 && p.matching == ICP_MATCH_KNN, seed, orders[i]};
-            if ((rc = launch_match(c, q))) return rc;
-            HIPCK(c, hipEventRecord(c->events[1 + 3 * i], c->stream));
-            if ((rc = launch_post_and_solve(c, sels[i], ns[i], d_st, nullptr, 1, c->events[2 + 3 * i]))) return rc;
-        } else {
+            q.work_slot = i;
+            int fused = 0;
+            if ((rc = launch_match(c, q, c->fuse_post ? &fused : nullptr))) return rc;
+            if (ev) HIPCK(c, hipEventRecord(c->events[1 + 3 * i], c->stream));
+            if ((rc = launch_post_and_solve(c, sels[i], ns[i], d_st, nullptr, 1, ev ? c->events[2 + 3 * i] : nullptr, fused))) return rc;
+        } else if (ev) {
             HIPCK(c, hipEventRecord(c->events[1 + 3 * i], c->stream));
             HIPCK(c, hipEventRecord(c->events[2 + 3 * i], c->stream));
         }
@@ -686,7 +747,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
             hipLaunchKernelGGL(k_rmse_finish, dim3(1), dim3(64), 0, c->stream, c->rmse_partials.as<double>(), 256, &d_st->rmse);
         }
         if (fontana && (rc = enqueue_fontana(c, &d_st->benchmark_error))) return rc;
-        HIPCK(c, hipEventRecord(c->events[3 + 3 * i], c->stream));
+        if (ev || i == iters - 1) HIPCK(c, hipEventRecord(c->events[3 + 3 * i], c->stream));
     }
     std::vector<icp_iter_stats> hs((size_t)iters);
     PoseState hp;
@@ -704,12 +765,20 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     }
     if (n_run) *n_run = iters;
     icp_timing& t = c->timing; memset(&t, 0, sizeof(t)); t.iterations = iters;
-    for (int i = 0; i < iters; i++) {
+    for (int i = 0; ev && i < iters; i++) {
         float a = 0, b = 0, d = 0;
         HIPCK(c, hipEventElapsedTime(&a, c->events[3 * i], c->events[1 + 3 * i]));
         HIPCK(c, hipEventElapsedTime(&b, c->events[1 + 3 * i], c->events[2 + 3 * i]));
         HIPCK(c, hipEventElapsedTime(&d, c->events[2 + 3 * i], c->events[3 + 3 * i]));
         t.match_ms += a; t.weight_reject_build_ms += b; t.solve_ms += d;
+        if (c->trace) fprintf(stderr, "[icp_hip] it %2d  n %d  match %.4f  post %.4f  solve %.4f ms\n", i, ns[i], a, b, d);
+    }
+    if (c->trace && c->work_counts.p && c->two_pass) {
+        std::vector<int> wc((size_t)iters);
+        HIPCK(c, hipMemcpy(wc.data(), c->work_counts.p, (size_t)iters * 4, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[icp_hip] tree walks per iteration:");
+        for (int i = 0; i < iters; i++) fprintf(stderr, " %d", wc[i]);
+        fprintf(stderr, "\n");
     }
     float tot = 0; HIPCK(c, hipEventElapsedTime(&tot, c->events[0], c->events[3 * iters])); t.total_ms = tot;
     if (status != ICP_OK) c->err = "no valid correspondences in at least one iteration (reference would hang in ASSERT)";
