@@ -119,7 +119,7 @@ struct KnnParams {
     icp_match_t* out; float* d2_out;                           // direct outputs (nseg == 1)
     unsigned long long* best64;                              // packed partial results (nseg > 1)
     int nseg;
-    int* nn_raw;                                             // [n] raw nearest index of this launch (BVH backend), seed of the next one
+    int* nn_raw;                                             // [n] position (8 * leaf + slot) of the nearest target of this launch (BVH backend), seed of the next one
     int use_prev;                                            // 1: nn_raw holds the previous iteration's result for the same queries
     float4* qstate;                                          // [n] (query xyz when last searched or verified, lower bound on the distance to every OTHER target)
     int incremental;                                         // 1: verify-and-skip with qstate (needs use_prev)
@@ -231,14 +231,20 @@ typedef BvhLeafT<3> BvhLeaf;
 
 // 4-wide node of the same tree with two binary levels collapsed: the boxes of the four grandchildren, SoA per axis (two
 // packed-f32 pairs each).  96 B / 192 B.  Half the dependent loads per query of the binary walk -- the search is bound by
-// the latency of that chain, not by bytes or flops.
-template <int DIM> struct BvhQuadT { float lo[DIM][4]; float hi[DIM][4]; };
+// the latency of that chain, not by bytes or flops.  128 B / 256 B.
+template <int DIM> struct BvhQuadT { float lo[DIM][4]; float hi[DIM][4]; float pad[DIM == 3 ? 8 : 16]; };   // padded to one / two 128-byte lines
+
+// Everything the loop needs about a matched target point in ONE 32-byte record, stored in kd (leaf) order -- position
+// pos = 8 * leaf + slot.  Neighbouring (Morton-sorted) queries match neighbouring positions, so the gather of the
+// correspondence (point, normal, colour) is one sector per query instead of seven scattered planes.
+struct TgtRec { float x, y, z; int idx; float nx, ny, nz; uint32_t rgba; };
 
 template <int DIM> struct CoordPtrs { const float* c[DIM]; };
 
 template <int DIM> struct BvhViewT {
     const BvhLeafT<DIM>* leaves;  // [max(n_leaves,1)] kd-ordered points, 8 per leaf; pads are +inf with index -1
     const BvhNodeT<DIM>* nodes;   // [Lp - 1] internal nodes in heap order (node k: children 2k+1, 2k+2; leaves start at Lp-1)
+    const TgtRec* recs;           // [8 * max(n_leaves,1)] point + normal + colour + original index by position
     const BvhQuadT<DIM>* qnodes;  // [(4^Lq - 1) / 3] 4-wide nodes, level l at offset (4^l - 1) / 3; the children of level Lq - 1 are the leaves
     int Lq;                       // 4-wide levels = ceil(log2(Lp) / 2)  (an odd binary depth gets a virtual root with one empty half)
     int n_valid;                  // finite target points in the tree
@@ -328,20 +334,26 @@ __global__ void k_bvh_level_keys(const CoordPtrs<DIM> cp, const int* __restrict_
 }
 
 template <int DIM>
-__global__ void k_bvh_gather(const CoordPtrs<DIM> cp, const int* __restrict__ sorted_idx, int n_valid, int n_slots, BvhLeafT<DIM>* __restrict__ leaves) {
+__global__ void k_bvh_gather(const CoordPtrs<DIM> cp, const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ nz, const uint32_t* __restrict__ rgba,
+                             const int* __restrict__ sorted_idx, int n_valid, int n_slots, BvhLeafT<DIM>* __restrict__ leaves, TgtRec* __restrict__ recs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
     BvhLeafT<DIM>* lf = leaves + (i / BVH_LEAF); const int t = i % BVH_LEAF;
+    TgtRec r; r.x = INFINITY; r.y = INFINITY; r.z = INFINITY; r.idx = -1; r.nx = 0.f; r.ny = 0.f; r.nz = 0.f; r.rgba = 0u;
     if (i < n_valid) {
         const int j = sorted_idx[i];
 #pragma unroll
         for (int k = 0; k < DIM; k++) lf->c[k][t] = cp.c[k][j];
         lf->idx[t] = j;
+        r.x = cp.c[0][j]; r.y = cp.c[1][j]; r.z = cp.c[2][j]; r.idx = j;
+        if (nx) { r.nx = nx[j]; r.ny = ny[j]; r.nz = nz[j]; }
+        if (rgba) r.rgba = rgba[j];
     } else {
 #pragma unroll
         for (int k = 0; k < DIM; k++) lf->c[k][t] = (k < 3) ? INFINITY : 0.f;
         lf->idx[t] = -1;
     }
+    recs[i] = r;
 }
 
 // Boxes of the children of the internal nodes [first, first + count), bottom-up.  child_is_leaf: children are leaves.
@@ -423,7 +435,7 @@ __device__ __forceinline__ f2 pair_lb(const BvhNodeT<DIM>* __restrict__ nd, cons
 // Evaluate the 8 points of a leaf against the lane's query; exact lexicographic (d2, lowest index) update.
 // best2 follows the smallest distance among all evaluated points OTHER than the current winner (see k_knn_bvh).
 template <int DIM>
-__device__ __forceinline__ void leaf_eval(const BvhLeafT<DIM>* __restrict__ lf, const f2* p2, float& best, int& bi, float& best2) {
+__device__ __forceinline__ void leaf_eval(const BvhLeafT<DIM>* __restrict__ lf, int leaf, const f2* p2, float& best, int& bi, int& bpos, float& best2) {
     float dd[BVH_LEAF];
     float m = FLT_MAX;
 #pragma unroll
@@ -446,7 +458,7 @@ __device__ __forceinline__ void leaf_eval(const BvhLeafT<DIM>* __restrict__ lf, 
             const bool take = (dd[t] < best) | ((dd[t] == best) & (j < bi));     // first minimum = lowest original index
             const float other = take ? best : ((j != bi) ? dd[t] : FLT_MAX);      // the dethroned winner, or a non-winning point
             best2 = fminf(best2, other);
-            best = take ? dd[t] : best; bi = take ? j : bi;
+            best = take ? dd[t] : best; bi = take ? j : bi; bpos = take ? leaf * BVH_LEAF + t : bpos;
         }
     } else best2 = fminf(best2, m);      // nobody here can win: all 8 are "others"
 }
@@ -456,14 +468,22 @@ __device__ __forceinline__ void leaf_eval(const BvhLeafT<DIM>* __restrict__ lf, 
 // with the same fp32 formula -- and the final (d2, index) is still the exact lexicographic minimum over ALL targets
 // (a box is skipped only if its lower bound exceeds the running best).
 template <int DIM>
-__device__ __forceinline__ void seed_from_previous(const int* __restrict__ nn_raw, int use_prev, const CoordPtrs<DIM>& tgt, int k, const float* p, float& best, int& bi) {
+__device__ __forceinline__ void seed_from_previous(const int* __restrict__ nn_pos, int use_prev, const BvhViewT<DIM>& bv, int k, const float* p, float& best, int& bi, int& bpos) {
     if (!use_prev) return;
-    const int j0 = nn_raw[k];
-    if (j0 < 0) return;
+    const int q0 = nn_pos[k];                             // POSITION (8 * leaf + slot) of the previous neighbour
+    if (q0 < 0) return;
+    float t[DIM]; int j0;
+    if (DIM == 3) { const float4 r = *(const float4*)(bv.recs + q0); t[0] = r.x; t[1] = r.y; t[2] = r.z; j0 = __float_as_int(r.w); }
+    else {
+        const BvhLeafT<DIM>* lf = bv.leaves + (q0 >> 3);
+#pragma unroll
+        for (int q = 0; q < DIM; q++) t[q] = lf->c[q][q0 & 7];
+        j0 = lf->idx[q0 & 7];
+    }
     float d = 0.f;
 #pragma unroll
-    for (int q = 0; q < DIM; q++) { const float e = p[q] - tgt.c[q][j0]; d = (q == 0) ? e * e : d + e * e; }
-    if (d < best) { best = d; bi = j0; }
+    for (int q = 0; q < DIM; q++) { const float e = p[q] - t[q]; d = (q == 0) ? e * e : d + e * e; }
+    if (d < best) { best = d; bi = j0; bpos = q0; }
 }
 
 // Per-lane traversal state of the complete binary tree in heap order: three registers -- depth, index within the level
@@ -479,34 +499,6 @@ __device__ __forceinline__ void trav_pop(TravState& st, const unsigned short* __
         const float lb = __uint_as_float((unsigned int)lb16[d * nthreads + tid] << 16);      // <= true bound
         if (!(lb * 0.99999f > best)) { st.idx = (st.idx >> (st.depth - d - 1)) ^ 1; st.depth = d + 1; st.alive = true; }
         else minlb = fminf(minlb, lb);                    // skipped subtree: everything in it is at least this far
-    }
-}
-
-// "Near child first" traversal to completion, "while-while" shape: busy lanes first descend through internal nodes,
-// then evaluate their leaves together.
-// best2 / minlb: smallest evaluated distance of a non-winner and smallest lower bound of a skipped subtree -- together a
-// lower bound on the squared distance from the query to every target other than the winner (for the incremental search).
-template <int DIM>
-__device__ __forceinline__ void trav_run(const BvhViewT<DIM>& bv, int tree_depth, const f2* p2, TravState& st,
-                                         float& best, int& bi, float& best2, float& minlb, unsigned short* __restrict__ lb16, int tid, int nthreads) {
-    while (st.alive) {
-        while (st.alive && st.depth < tree_depth) {
-            const f2 l = pair_lb<DIM>(bv.nodes + ((1 << st.depth) - 1 + st.idx), p2);
-            const bool swap = l.y < l.x;                  // child 1 is nearer
-            const float ln = swap ? l.y : l.x, lf = swap ? l.x : l.y;
-            const bool take_near = !(ln * 0.99999f > best), take_far = !(lf * 0.99999f > best);
-            minlb = fminf(minlb, take_near ? (take_far ? FLT_MAX : lf) : ln);     // whatever is skipped right here
-            if (take_near) {
-                if (take_far) { lb16[st.depth * nthreads + tid] = (unsigned short)(__float_as_uint(lf) >> 16); st.pending |= 1u << st.depth; }
-                st.idx = 2 * st.idx + (swap ? 1 : 0); st.depth++;
-            } else st.alive = false;                      // both children pruned (lf >= ln)
-            trav_pop(st, lb16, tid, nthreads, best, minlb);
-        }
-        if (st.alive) {
-            leaf_eval<DIM>(bv.leaves + st.idx, p2, best, bi, best2);
-            st.alive = false;
-            trav_pop(st, lb16, tid, nthreads, best, minlb);
-        }
     }
 }
 
@@ -550,9 +542,32 @@ __device__ __forceinline__ void quad_pop(QuadState& st, const uint2* __restrict_
     }
 }
 
+// The walk is a chain of dependent loads, each a trip to L2 or HBM.  A seeded query already knows where it will most
+// likely end up: in or next to the leaf of its previous neighbour, whose ancestors are known arithmetically in the implicit
+// layout.  Touching that whole root-to-leaf path up front turns the chain of misses into ONE round of parallel misses followed
+// by cache hits.  (The lowest 8 levels; anything above is shared by everybody and hot.)
+template <int DIM>
+__device__ __forceinline__ unsigned int quad_prefetch_path(const BvhViewT<DIM>& bv, int leaf) {
+    // plain loads whose values are only consumed (by an empty asm) AFTER the walk: nothing waits for them specially, they
+    // simply travel together with the walk's first node load
+    unsigned int sink = *(const unsigned int*)(bv.leaves + leaf);
+    if (DIM == 6) sink |= *((const unsigned int*)(bv.leaves + leaf) + 32);
+    unsigned int t[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {                         // branch-free (levels above the root clamp to the root): the loads issue back to back
+        const int L = max(bv.Lq - 1 - u, 0), sh = min(2 * (u + 1), 2 * bv.Lq);
+        const unsigned int* nd = (const unsigned int*)(bv.qnodes + ((0x5555555555555555ull & ((1ull << (2 * L)) - 1ull)) + (unsigned long long)(leaf >> sh)));
+        t[u] = nd[31];
+        if (DIM == 6) t[u] |= nd[63];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) sink |= t[u];
+    return sink;
+}
+
 template <int DIM>
 __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const f2* p2, QuadState& st,
-                                         float& best, int& bi, float& best2, float& minlb, uint2* __restrict__ lbq, int tid, int nthreads) {
+                                         float& best, int& bi, int& bpos, float& best2, float& minlb, uint2* __restrict__ lbq, int tid, int nthreads) {
     const int Lq = bv.Lq;
     while (st.alive) {
         while (st.alive && st.L < Lq) {
@@ -576,7 +591,7 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const f2* p2, 
             quad_pop(st, lbq, tid, nthreads, best, minlb);
         }
         if (st.alive) {
-            leaf_eval<DIM>(bv.leaves + st.idx, p2, best, bi, best2);
+            leaf_eval<DIM>(bv.leaves + st.idx, st.idx, p2, best, bi, bpos, best2);
             st.alive = false;
             quad_pop(st, lbq, tid, nthreads, best, minlb);
         }
@@ -613,8 +628,8 @@ __device__ __forceinline__ void knn_load_query(const KnnParams& kp, int k, float
 // distance formula (< 4e-7), so the result is bit-identical to a full search; otherwise a full search runs.
 // Seeds (best, bi) with the previous neighbour either way.
 template <int DIM>
-__device__ __forceinline__ bool knn_try_verify(const KnnParams& kp, const BvhViewT<DIM>& bv, int k, const float* p, float& best, int& bi, float& lb_others) {
-    seed_from_previous<DIM>(kp.nn_raw, kp.use_prev, bv.tgt, k, p, best, bi);
+__device__ __forceinline__ bool knn_try_verify(const KnnParams& kp, const BvhViewT<DIM>& bv, int k, const float* p, float& best, int& bi, int& bpos, float& lb_others) {
+    seed_from_previous<DIM>(kp.nn_raw, kp.use_prev, bv, k, p, best, bi, bpos);
     if (kp.incremental && kp.use_prev && bi >= 0) {
         const float4 s = kp.qstate[k];
         const float ex = p[0] - s.x, ey = p[1] - s.y, ez = p[2] - s.z;
@@ -626,31 +641,34 @@ __device__ __forceinline__ bool knn_try_verify(const KnnParams& kp, const BvhVie
 }
 
 template <int DIM>
-__device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, const float* p, float best, int bi, float lb_others) {
+__device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, const float* p, float best, int bpos, float lb_others) {
     if (kp.qstate) { float4 s; s.x = p[0]; s.y = p[1]; s.z = p[2]; s.w = lb_others; kp.qstate[k] = s; }
-    if (kp.nn_raw) kp.nn_raw[k] = bi;
+    if (kp.nn_raw) kp.nn_raw[k] = bpos;
     if (kp.d2_out) kp.d2_out[k] = best;
 }
 
 template <int DIM>
 __device__ __forceinline__ void knn_bvh_query(const KnnParams& kp, const BvhViewT<DIM>& bv, int k, uint2* __restrict__ lbq, int tid,
-                                              float& best, int& bi) {
+                                              float& best, int& bi, int& bpos) {
     float p[DIM];
     knn_load_query<DIM>(kp, k, p);
-    best = FLT_MAX; bi = -1;
+    best = FLT_MAX; bi = -1; bpos = -1;
     float lb_others = 0.f;               // lower bound on the (real) distance from p to every target except bi
     if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
-        if (!knn_try_verify<DIM>(kp, bv, k, p, best, bi, lb_others)) {
+        if (!knn_try_verify<DIM>(kp, bv, k, p, best, bi, bpos, lb_others)) {
             f2 p2[DIM];
 #pragma unroll
             for (int q = 0; q < DIM; q++) { p2[q].x = p[q]; p2[q].y = p[q]; }
             float best2 = FLT_MAX, minlb = FLT_MAX;
+            unsigned int touched = 0u;
+            if (bpos >= 0) touched = quad_prefetch_path<DIM>(bv, bpos >> 3);
             QuadState st; st.L = 0; st.idx = 0; st.pending = 0ull; st.alive = true;
-            quad_run<DIM>(bv, p2, st, best, bi, best2, minlb, lbq, tid, BVH_THREADS);
+            quad_run<DIM>(bv, p2, st, best, bi, bpos, best2, minlb, lbq, tid, BVH_THREADS);
+            asm volatile("" ::"v"(touched));
             lb_others = sqrtf(fminf(best2, minlb)) * 0.999999f;
         }
     }
-    knn_store_state<DIM>(kp, k, p, best, bi, lb_others);
+    knn_store_state<DIM>(kp, k, p, best, bpos, lb_others);
 }
 
 // Which query does this lane serve?  Either position t of the (Morton-sorted) query order, or -- second pass of the
@@ -674,8 +692,8 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, con
     const int tid = threadIdx.x;
     const int k = knn_bvh_lane_query(kp, qorder, tid);
     if (k < 0) return;
-    float best; int bi;
-    knn_bvh_query<DIM>(kp, bv, k, bvh_lbq, tid, best, bi);
+    float best; int bi, bpos;
+    knn_bvh_query<DIM>(kp, bv, k, bvh_lbq, tid, best, bi, bpos);
     icp_match_t m;
     if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
     kp.out[k] = m;
@@ -694,12 +712,12 @@ __global__ __launch_bounds__(VERIFY_THREADS) void k_knn_verify(const KnnParams k
         k = qorder ? qorder[t] : t;
         float p[DIM];
         knn_load_query<DIM>(kp, k, p);
-        float best = FLT_MAX, lb_others = 0.f; int bi = -1;
+        float best = FLT_MAX, lb_others = 0.f; int bi = -1, bpos = -1;
         if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
-            push = !knn_try_verify<DIM>(kp, bv, k, p, best, bi, lb_others);
+            push = !knn_try_verify<DIM>(kp, bv, k, p, best, bi, bpos, lb_others);
         }
         if (!push) {
-            knn_store_state<DIM>(kp, k, p, best, bi, lb_others);
+            knn_store_state<DIM>(kp, k, p, best, bpos, lb_others);
             icp_match_t m;
             if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
             kp.out[k] = m;
@@ -806,6 +824,16 @@ __global__ __launch_bounds__(BVH_THREADS) void k_normals_knn(const BvhViewT<3> b
     if (curv_out) curv_out[i] = curv;
 }
 
+// out[t] = in[idx[t]] (one plane of a cloud) / out[t] = sel[order[t]]: the one-off physical permutation of the source into Morton order
+__global__ void k_gather_f32(const float* __restrict__ in, const int* __restrict__ idx, int n, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x; if (t < n) out[t] = in[idx[t]];
+}
+__global__ void k_gather_u32(const uint32_t* __restrict__ in, const int* __restrict__ idx, int n, uint32_t* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x; if (t < n) out[t] = in[idx[t]];
+}
+__global__ void k_compose_idx(const int* __restrict__ sel, const int* __restrict__ order, int n, int* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x; if (t < n) out[t] = sel ? sel[order[t]] : order[t];
+}
 __global__ void k_iota(int* p, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = i; }
 
 // Morton key of the (untransformed) query points -> spatially coherent waves for k_knn_bvh.
@@ -927,11 +955,18 @@ __device__ __forceinline__ double block_reduce_wide(double (&v)[NV], double* lds
     return tot;
 }
 
-// Rows of the reference's 4n x 6 system in fp32, then their contribution to J^T J (upper triangle,
-// 21) and J^T r (6) in fp64.  kind 0: point-to-plane (ICPOptimizer.h:698-750); kind 1: symmetric
-// (ICPOptimizer.h:806-852, s/d already centred, n = n_t + n_s).
-__device__ __forceinline__ void accumulate_rows(int kind, float s0, float s1, float s2, float d0, float d1, float d2,
-                                                float n0, float n1, float n2, float w, double* acc /* 27 */) {
+// Rows of the reference's 4n x 6 system in fp32 (kind 0: point-to-plane, ICPOptimizer.h:698-750; kind 1: symmetric,
+// ICPOptimizer.h:806-852, s/d already centred, n = n_t + n_s).  Row 0 is dense and scaled by LAMBDA_PLANE/SYMMETRIC = 1 times
+// the weight; rows 1-3 are the point rows [0, s2, -s1, 1,0,0 | d0-s0], [-s2, 0, s0, 0,1,0 | d1-s1], [s1, -s0, 0, 0,0,1 | d2-s2]
+// scaled by LAMBDA_POINT = 0.1 times the weight (:737-750 / :839-852) -- kept as their non-zero entries only.
+struct RowTerms {
+    float r0[7];                 // row 0: 6 coefficients + right-hand side
+    float p1, p2, rr1;           // row 1: columns 1, 2 (+ g at column 3), rhs
+    float q0, q2, rr2;           // row 2: columns 0, 2 (+ g at column 4), rhs
+    float t0, t1, rr3;           // row 3: columns 0, 1 (+ g at column 5), rhs
+    float g;                     // 1 * f1
+};
+__device__ __forceinline__ void build_rows(int kind, float s0, float s1, float s2, float d0, float d1, float d2, float n0, float n1, float n2, float w, RowTerms& R) {
     float A0[6], b0;
     if (kind == 0) {
         A0[0] = n2 * s1 - n1 * s2; A0[1] = n0 * s2 - n2 * s0; A0[2] = n1 * s0 - n0 * s1;
@@ -943,42 +978,62 @@ __device__ __forceinline__ void accumulate_rows(int kind, float s0, float s1, fl
         b0 = g0 * n0 + (g1 * n1 + g2 * n2);
     }
     A0[3] = n0; A0[4] = n1; A0[5] = n2;
-    const float f0 = 1.0f * w, f1 = 0.1f * w;             // LAMBDA_PLANE/SYMMETRIC = 1, LAMBDA_POINT = 0.1 (:737-738,:839-840)
-    // row 0: dense, scaled by f0 (:740-741 / :842-843)
-    double r0[6];
+    const float f0 = 1.0f * w, f1 = 0.1f * w;
 #pragma unroll
-    for (int c = 0; c < 6; c++) r0[c] = (double)(A0[c] * f0);
-    const double rb0 = (double)(b0 * f0);
+    for (int c = 0; c < 6; c++) R.r0[c] = A0[c] * f0;
+    R.r0[6] = b0 * f0;
+    R.g = 1.f * f1;
+    R.p1 = s2 * f1; R.p2 = (-s1) * f1; R.rr1 = (d0 - s0) * f1;
+    R.q0 = (-s2) * f1; R.q2 = s0 * f1; R.rr2 = (d1 - s1) * f1;
+    R.t0 = s1 * f1; R.t1 = (-s0) * f1; R.rr3 = (d2 - s2) * f1;
+}
+
+// Contribution of one point's rows to slot A of [J^T J upper triangle (21) | J^T r (6)], in fp64, rows added in order 0..3.
+// For finite weights the zero entries of rows 1-3 contribute +0.0 in the dense form, so these sums are exactly those of the
+// dense 4n x 6 system.  Upper-triangle slot of (a, c), a <= c: a * 6 - a (a - 1) / 2 + (c - a).
+template <int A>
+__device__ __forceinline__ double row_slot(const RowTerms& R) {
+    constexpr int ta = A < 6 ? 0 : A < 11 ? 1 : A < 15 ? 2 : A < 18 ? 3 : A < 20 ? 4 : A < 21 ? 5 : A - 21;      // row index a (or a of J^T r)
+    constexpr int tc = A < 21 ? ta + (A - (ta * 6 - ta * (ta - 1) / 2)) : 6;                                      // column c (6 = rhs)
+    double v = (double)R.r0[ta] * (double)R.r0[tc];
+    // row 1: entries at columns 1 (p1), 2 (p2), 3 (g), rhs rr1
     {
-        int q = 0;
-#pragma unroll
-        for (int a = 0; a < 6; a++) {
-#pragma unroll
-            for (int c = a; c < 6; c++) { acc[q] += r0[a] * r0[c]; q++; }
-        }
-#pragma unroll
-        for (int a = 0; a < 6; a++) acc[21 + a] += r0[a] * rb0;
+        constexpr bool ha = ta == 1 || ta == 2 || ta == 3, hc = tc == 1 || tc == 2 || tc == 3 || tc == 6;
+        if (ha && hc) v += (double)(ta == 1 ? R.p1 : ta == 2 ? R.p2 : R.g) * (double)(tc == 1 ? R.p1 : tc == 2 ? R.p2 : tc == 3 ? R.g : R.rr1);
     }
-    // rows 1-3: the point rows [0, s2, -s1, 1,0,0 | d0-s0], [-s2, 0, s0, 0,1,0 | d1-s1], [s1, -s0, 0, 0,0,1 | d2-s2], each scaled by
-    // f1 (:743-750 / :845-852).  Only their non-zero entries are accumulated (for finite weights the zero entries contribute
-    // +0.0 in the dense form), in the same row order, so the fp64 sums are exactly those of the dense 4n x 6 system.
-    // upper-triangle slots: (0,0)=0 (0,1)=1 (0,2)=2 (0,4)=4 (0,5)=5 (1,1)=6 (1,2)=7 (1,3)=8 (1,5)=10 (2,2)=11 (2,3)=12 (2,4)=13 (3,3)=15 (4,4)=18 (5,5)=20
-    const double g = (double)(1.f * f1);
-    {   // row 1
-        const double p1 = (double)(s2 * f1), p2 = (double)((-s1) * f1), rr = (double)((d0 - s0) * f1);
-        acc[6] += p1 * p1; acc[7] += p1 * p2; acc[8] += p1 * g; acc[11] += p2 * p2; acc[12] += p2 * g; acc[15] += g * g;
-        acc[21 + 1] += p1 * rr; acc[21 + 2] += p2 * rr; acc[21 + 3] += g * rr;
+    // row 2: columns 0 (q0), 2 (q2), 4 (g), rhs rr2
+    {
+        constexpr bool ha = ta == 0 || ta == 2 || ta == 4, hc = tc == 0 || tc == 2 || tc == 4 || tc == 6;
+        if (ha && hc) v += (double)(ta == 0 ? R.q0 : ta == 2 ? R.q2 : R.g) * (double)(tc == 0 ? R.q0 : tc == 2 ? R.q2 : tc == 4 ? R.g : R.rr2);
     }
-    {   // row 2
-        const double q0 = (double)((-s2) * f1), q2 = (double)(s0 * f1), rr = (double)((d1 - s1) * f1);
-        acc[0] += q0 * q0; acc[2] += q0 * q2; acc[4] += q0 * g; acc[11] += q2 * q2; acc[13] += q2 * g; acc[18] += g * g;
-        acc[21 + 0] += q0 * rr; acc[21 + 2] += q2 * rr; acc[21 + 4] += g * rr;
+    // row 3: columns 0 (t0), 1 (t1), 5 (g), rhs rr3
+    {
+        constexpr bool ha = ta == 0 || ta == 1 || ta == 5, hc = tc == 0 || tc == 1 || tc == 5 || tc == 6;
+        if (ha && hc) v += (double)(ta == 0 ? R.t0 : ta == 1 ? R.t1 : R.g) * (double)(tc == 0 ? R.t0 : tc == 1 ? R.t1 : tc == 5 ? R.g : R.rr3);
     }
-    {   // row 3
-        const double t0 = (double)(s1 * f1), t1 = (double)((-s0) * f1), rr = (double)((d2 - s2) * f1);
-        acc[0] += t0 * t0; acc[1] += t0 * t1; acc[5] += t0 * g; acc[6] += t1 * t1; acc[10] += t1 * g; acc[20] += g * g;
-        acc[21 + 0] += t0 * rr; acc[21 + 1] += t1 * rr; acc[21 + 5] += g * rr;
+    return v;
+}
+template <int A>
+__device__ __forceinline__ void add_row_slots(const RowTerms& R, double* acc) {
+    if constexpr (A < 27) {
+        // same sequence of additions per slot as the row-by-row accumulation: acc += row0 term, += row1 term, ...
+        constexpr int ta = A < 6 ? 0 : A < 11 ? 1 : A < 15 ? 2 : A < 18 ? 3 : A < 20 ? 4 : A < 21 ? 5 : A - 21;
+        constexpr int tc = A < 21 ? ta + (A - (ta * 6 - ta * (ta - 1) / 2)) : 6;
+        acc[A] += (double)R.r0[ta] * (double)R.r0[tc];
+        { constexpr bool ha = ta == 1 || ta == 2 || ta == 3, hc = tc == 1 || tc == 2 || tc == 3 || tc == 6;
+          if (ha && hc) acc[A] += (double)(ta == 1 ? R.p1 : ta == 2 ? R.p2 : R.g) * (double)(tc == 1 ? R.p1 : tc == 2 ? R.p2 : tc == 3 ? R.g : R.rr1); }
+        { constexpr bool ha = ta == 0 || ta == 2 || ta == 4, hc = tc == 0 || tc == 2 || tc == 4 || tc == 6;
+          if (ha && hc) acc[A] += (double)(ta == 0 ? R.q0 : ta == 2 ? R.q2 : R.g) * (double)(tc == 0 ? R.q0 : tc == 2 ? R.q2 : tc == 4 ? R.g : R.rr2); }
+        { constexpr bool ha = ta == 0 || ta == 1 || ta == 5, hc = tc == 0 || tc == 1 || tc == 5 || tc == 6;
+          if (ha && hc) acc[A] += (double)(ta == 0 ? R.t0 : ta == 1 ? R.t1 : R.g) * (double)(tc == 0 ? R.t0 : tc == 1 ? R.t1 : tc == 5 ? R.g : R.rr3); }
+        add_row_slots<A + 1>(R, acc);
     }
+}
+__device__ __forceinline__ void accumulate_rows(int kind, float s0, float s1, float s2, float d0, float d1, float d2,
+                                                float n0, float n1, float n2, float w, double* acc /* 27 */) {
+    RowTerms R;
+    build_rows(kind, s0, s1, s2, d0, d1, d2, n0, n1, n2, w, R);
+    add_row_slots<0>(R, acc);
 }
 
 struct PostParams {
@@ -994,19 +1049,17 @@ struct PostParams {
     double* partials;            // [NSUM][gridDim.x]: sum a of block b at a * gridDim.x + b (the reducer reads rows contiguously)
 };
 
-// Weight, reject, filter and accumulate ONE correspondence (source position k, match m after matching): the body of
-// applyWeights / pruneCorrespondences / the validity filter / the system build.  Writes the final Match back.
-__device__ __forceinline__ void post_point(const PostParams& pp, int k, icp_match_t m, double* acc /* 34 */) {
-    if (m.idx < 0) return;
+// Weight, reject and filter ONE correspondence (source position k, match m after matching, matched target point d / normal nt /
+// colour tcol): the body of applyWeights / pruneCorrespondences / the validity filter.  Writes the final Match back; returns
+// whether the pair enters the system, with the transformed source point and the weight.  post_core adds the system build.
+__device__ __forceinline__ bool post_eval(const PostParams& pp, int k, icp_match_t m, float d0, float d1, float d2, float nt0, float nt1, float nt2, uint32_t tcol,
+                                          float& s0, float& s1, float& s2, float& w) {
     const float* __restrict__ P = pp.ps->pose;
     const float* __restrict__ N = pp.ps->nmat;
     const int i = pp.sel ? pp.sel[k] : k;
-    float s0, s1, s2, ns0, ns1, ns2;
+    float ns0, ns1, ns2;
     xform_point(P, pp.sx[i], pp.sy[i], pp.sz[i], s0, s1, s2);
     xform_normal(N, pp.snx[i], pp.sny[i], pp.snz[i], ns0, ns1, ns2);
-    const int j = m.idx;
-    const float d0 = pp.tx[j], d1 = pp.ty[j], d2 = pp.tz[j];
-    const float nt0 = pp.tnx[j], nt1 = pp.tny[j], nt2 = pp.tnz[j];
     const bool fin_sd = finite3(s0, s1, s2) && finite3(d0, d1, d2);
     // ---- applyWeights, weighting.h:44-90 ----
     if (pp.weighting != ICP_WEIGHT_CONSTANT) {
@@ -1023,7 +1076,7 @@ __device__ __forceinline__ void post_point(const PostParams& pp, int k, icp_matc
                 wnew += ns0 * nt0 + (ns1 * nt1 + ns2 * nt2);   // weighting.h:24 (Eigen dot tree)
         }
         if (pp.weighting == ICP_WEIGHT_COLORS) {
-            const uint32_t a = pp.srgba[i], b = pp.trgba[j];
+            const uint32_t a = pp.srgba[i], b = tcol;
             const int e0 = (int)(uint8_t)((a & 0xFF) - (b & 0xFF));           // weighting.h:28 uint8 wrap-around
             const int e1 = (int)(uint8_t)(((a >> 8) & 0xFF) - ((b >> 8) & 0xFF));
             const int e2 = (int)(uint8_t)(((a >> 16) & 0xFF) - ((b >> 16) & 0xFF));
@@ -1042,8 +1095,13 @@ __device__ __forceinline__ void post_point(const PostParams& pp, int k, icp_matc
         if (c >= -1.0f && c <= pp.cos_reject) m.idx = -1;
     }
     pp.matches[k] = m;
-    if (m.idx < 0 || !fin_sd) return;                      // ICPOptimizer.h:596-598
-    const float w = m.weight;
+    w = m.weight;
+    return m.idx >= 0 && fin_sd;                           // ICPOptimizer.h:596-598
+}
+__device__ __forceinline__ void post_core(const PostParams& pp, int k, icp_match_t m, float d0, float d1, float d2, float nt0, float nt1, float nt2, uint32_t tcol,
+                                          double* acc /* 34 */) {
+    float s0, s1, s2, w;
+    if (!post_eval(pp, k, m, d0, d1, d2, nt0, nt1, nt2, tcol, s0, s1, s2, w)) return;
     acc[SUM_N] += 1.0;
     acc[SUM_S] += (double)s0; acc[SUM_S + 1] += (double)s1; acc[SUM_S + 2] += (double)s2;
     acc[SUM_D] += (double)d0; acc[SUM_D + 1] += (double)d1; acc[SUM_D + 2] += (double)d2;
@@ -1061,6 +1119,13 @@ __device__ __forceinline__ void post_point(const PostParams& pp, int k, icp_matc
     }
 }
 
+// The same, with the matched target gathered from the target planes by original index (scan / projective matchers).
+__device__ __forceinline__ void post_point(const PostParams& pp, int k, icp_match_t m, double* acc /* 34 */) {
+    if (m.idx < 0) return;
+    const int j = m.idx;
+    post_core(pp, k, m, pp.tx[j], pp.ty[j], pp.tz[j], pp.tnx[j], pp.tny[j], pp.tnz[j], pp.weighting == ICP_WEIGHT_COLORS ? pp.trgba[j] : 0u, acc);
+}
+
 // One fused pass over the correspondences (weight, reject, filter, accumulate) -- used after the scan / projective matchers.
 __global__ __launch_bounds__(POST_THREADS) void k_post(const PostParams pp) {
     __shared__ double lds[4 * 34 * 17];
@@ -1073,29 +1138,86 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(const PostParams pp) {
 }
 
 // BVH k-NN with the post stage as its epilogue: the lane that found the neighbour of query k immediately weighs / rejects /
-// accumulates it, so matches never make a round trip through memory and the gathers of the post stage overlap with other
-// waves' tree walks.  One kernel instead of two per iteration.  Block partials keep the fixed-order reduction contract.
+// accumulates it, so matches never make a round trip through memory.  One kernel instead of two per iteration.  Each lane
+// has exactly one pair, so the 34 sums are not accumulated in registers first: every value is produced, folded 64 -> 16 lanes
+// with two shuffles and parked in LDS right away (groups separated by scheduling barriers), which keeps the kernel at the
+// register budget of the walk.  Block partials keep the fixed-order reduction contract.
+__device__ __forceinline__ void fold_store(double x, double* lds, int a, int lane, int w) {
+    x += __shfl_down(x, 32, WAVE);
+    x += __shfl_down(x, 16, WAVE);
+    if (lane < 16) lds[(w * 34 + a) * 17 + lane] = x;
+}
+template <int A, int END>
+__device__ __forceinline__ void fold_row_slots(const RowTerms& R, bool valid, double* lds, int lane, int w) {
+    if constexpr (A < END) {
+        fold_store(valid ? row_slot<A>(R) : 0.0, lds, SUM_M + A, lane, w);
+        fold_row_slots<A + 1, END>(R, valid, lds, lane, w);
+    }
+}
 template <int DIM>
 __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {
     extern __shared__ uint2 bvh_lbq[];                    // [Lq][BVH_THREADS] pending-sibling bounds; reused by the reduction
     constexpr int NW = BVH_THREADS / WAVE;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int k = knn_bvh_lane_query(kp, qorder, tid);
-    double acc[34];
-#pragma unroll
-    for (int a = 0; a < 34; a++) acc[a] = 0.0;
+    bool valid = false;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, wt = 0.f;
     if (k >= 0) {
-        float best; int bi;
-        knn_bvh_query<DIM>(kp, bv, k, bvh_lbq, tid, best, bi);
+        float best; int bi, bpos;
+        knn_bvh_query<DIM>(kp, bv, k, bvh_lbq, tid, best, bi, bpos);
         icp_match_t m;
         if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
-        if (m.idx < 0) pp.matches[k] = m; else post_point(pp, k, m, acc);
+        if (m.idx < 0) pp.matches[k] = m;
+        else {
+            const float4 ra = *(const float4*)(bv.recs + bpos), rb = *((const float4*)(bv.recs + bpos) + 1);      // one 32-byte record
+            d0 = ra.x; d1 = ra.y; d2 = ra.z; n0 = rb.x; n1 = rb.y; n2 = rb.z;
+            valid = post_eval(pp, k, m, d0, d1, d2, n0, n1, n2, __float_as_uint(rb.w), s0, s1, s2, wt);
+        }
     }
     __syncthreads();                                      // the traversal stacks are dead: reuse LDS for the reduction
     double* lds = (double*)bvh_lbq;
-    const double tot = block_reduce_wide<34, NW>(acc, lds);
-    const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);                  // partial slot = logical block -> fixed summation order
-    if (tid < 34) pp.partials[(size_t)tid * gridDim.x + lb] = tot;
+    fold_store(valid ? 1.0 : 0.0, lds, SUM_N, lane, w);
+    fold_store(valid ? (double)s0 : 0.0, lds, SUM_S, lane, w); fold_store(valid ? (double)s1 : 0.0, lds, SUM_S + 1, lane, w); fold_store(valid ? (double)s2 : 0.0, lds, SUM_S + 2, lane, w);
+    fold_store(valid ? (double)d0 : 0.0, lds, SUM_D, lane, w); fold_store(valid ? (double)d1 : 0.0, lds, SUM_D + 1, lane, w); fold_store(valid ? (double)d2 : 0.0, lds, SUM_D + 2, lane, w);
+    if (pp.metric == ICP_METRIC_POINT_TO_PLANE) {
+        RowTerms R;
+        build_rows(0, s0, s1, s2, d0, d1, d2, n0, n1, n2, wt, R);
+        fold_row_slots<0, 7>(R, valid, lds, lane, w);   __builtin_amdgcn_sched_barrier(0);
+        fold_row_slots<7, 14>(R, valid, lds, lane, w);  __builtin_amdgcn_sched_barrier(0);
+        fold_row_slots<14, 21>(R, valid, lds, lane, w); __builtin_amdgcn_sched_barrier(0);
+        fold_row_slots<21, 27>(R, valid, lds, lane, w);
+    } else {                                              // point-to-point moments (see post_core)
+        const double wd = (double)wt;
+        const double ws[3] = {wd * s0, wd * s1, wd * s2};
+        const float dd[3] = {d0, d1, d2};
+        fold_store(valid ? wd : 0.0, lds, SUM_M, lane, w);
+#pragma unroll
+        for (int q = 0; q < 3; q++) fold_store(valid ? ws[q] : 0.0, lds, SUM_M + 1 + q, lane, w);
+#pragma unroll
+        for (int q = 0; q < 3; q++) fold_store(valid ? wd * dd[q] : 0.0, lds, SUM_M + 4 + q, lane, w);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) fold_store(valid ? (double)dd[j] * ws[q] : 0.0, lds, SUM_M + 7 + j * 3 + q, lane, w);
+        }
+#pragma unroll
+        for (int q = 16; q < 27; q++) fold_store(0.0, lds, SUM_M + q, lane, w);
+    }
+    __syncthreads();
+    if (tid < 34) {
+        double tot = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < NW; ww++) {
+            const double* row = lds + (ww * 34 + tid) * 17;
+            double part = 0.0;
+#pragma unroll
+            for (int l = 0; l < 16; l++) part += row[l];
+            tot += part;
+        }
+        const int lb = kp.work_items ? (int)blockIdx.x : xcd_contiguous_block(blockIdx.x, gridDim.x);             // partial slot = logical block -> fixed summation order
+        pp.partials[(size_t)tid * gridDim.x + lb] = tot;
+    }
 }
 
 // Second pass of the symmetric objective: rows need the means of the valid pairs first

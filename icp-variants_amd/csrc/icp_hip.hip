@@ -42,13 +42,17 @@ struct Cloud {
     bool has_normals = false, has_colors = false;
 };
 
-struct Level { DevBuf idx; DevBuf order; int n = 0; };   // selection (original indices) + Morton order of its positions
+// One resolution level of the source: the selection (original indices, increasing), and -- for the BVH matcher -- a physical
+// copy of the selected points in Morton order, so that everything the ICP loop touches per query (source planes, search
+// state, matches) is indexed by the same sorted position and streams coalesced.  factor 0 = the whole cloud, unfiltered.
+struct Level { DevBuf idx; DevBuf order; DevBuf sorted_idx; Cloud sorted; bool sorted_valid = false; int n = 0; };
 
 // LBVH over the target (buildIndex): device buffers + the host-side facts needed to launch the build.
 struct Bvh {
     bool valid = false;
     int n_valid = 0, n_leaves = 0, Lp = 1;
-    DevBuf keys, keys2, vals, vals2, temp, leaves, nodes, qnodes, lvl, wbox;
+    DevBuf keys, keys2, vals, vals2, temp, leaves, recs, nodes, qnodes, lvl, wbox;
+    const Cloud* attrs = nullptr;                     // cloud whose normals / colours go into the records (nullptr: none)
     int Lq = 0;                                       // 4-wide levels
     std::vector<int> finite_idx;                     // indices of the finite target points, increasing
     double build_ms = 0.0;
@@ -70,7 +74,7 @@ struct icp_ctx {
     Bvh bvh, bvh6;                       // exact kd-ordered BVH of the target over xyz / over xyz+rgb (knn_backend == ICP_KNN_LBVH)
     std::vector<uint8_t> src_valid;      // host mask: finite point && finite normal (PointCloud.h:334)
     float src_lo[3] = {0, 0, 0}, src_hi[3] = {0, 0, 0};   // bounding box of the finite source points
-    DevBuf order_full, okeys, okeys2, ovals, otemp; bool order_full_valid = false;   // Morton order of the full source
+    DevBuf okeys, okeys2, ovals, otemp;  // scratch of the Morton sort of the queries
     std::map<int, Level> levels;         // multires selections by decimation factor
     DevBuf sel_lists, sel_counts, sel_blocks;            // RANDOM_SAMPLING: per-iteration index lists, their sizes, scan scratch
     DevBuf qstate;                                       // incremental k-NN: per-query position + bound on the other targets
@@ -96,6 +100,7 @@ int ensure(icp_ctx* c, DevBuf& b, size_t bytes) {
 }
 void release(DevBuf& b) { if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; } }
 void release(Cloud& c) { release(c.x); release(c.y); release(c.z); release(c.nx); release(c.ny); release(c.nz); release(c.cr); release(c.cg); release(c.cb); release(c.rgba); }
+void release(Level& lv) { release(lv.idx); release(lv.order); release(lv.sorted_idx); release(lv.sorted); lv.sorted_valid = false; }
 
 // Largest float c with (double)acosf(c) > 60*pi/180 on THIS host's libm: the device rejection test
 // `c <= cos_reject` is then bit-identical to the reference's `acos(c) > threshold` (ICPOptimizer.h:161,170)
@@ -166,7 +171,7 @@ int write_pose(icp_ctx* c, const float pose[16]) {
     return ICP_OK;
 }
 
-struct QuerySet { const Cloud* cl; const int* sel; int n; int pretransformed; bool use_colors; bool seed_prev; const int* order; int work_slot = -1; };
+struct QuerySet { const Cloud* cl; const int* sel; int n; int pretransformed; bool use_colors; bool seed_prev; const int* order; int work_slot = -1; };   // cl/sel: also what the post stage reads
 
 int ensure_match_buffers(icp_ctx* c, int n) {
     int rc;
@@ -194,16 +199,6 @@ int build_query_order(icp_ctx* c, const int* d_sel, int n, DevBuf& out) {
     return ICP_OK;
 }
 
-// Morton order of the whole resident source (packet traversal), built lazily; nullptr when the packet kernel is not in use.
-int get_full_order(icp_ctx* c, const int** out) {
-    *out = nullptr;
-    const icp_params& p = c->prm;
-    if (!(p.matching == ICP_MATCH_KNN && p.knn_backend == ICP_KNN_LBVH) || c->src.n <= 0) return ICP_OK;
-    if (!c->order_full_valid) { int rc; if ((rc = build_query_order(c, nullptr, c->src.n, c->order_full))) return rc; c->order_full_valid = true; }
-    *out = c->order_full.as<int>();
-    return ICP_OK;
-}
-
 // Build the kd-ordered BVH of the resident target on the device (once per icp_set_target; = buildIndex).
 template <int DIM>
 int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
@@ -223,6 +218,7 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
     if ((rc = ensure(c, b.vals, (size_t)cap * 4))) return rc;
     if ((rc = ensure(c, b.vals2, (size_t)cap * 4))) return rc;
     if ((rc = ensure(c, b.leaves, (size_t)(n_slots / BVH_LEAF) * sizeof(BvhLeafT<DIM>)))) return rc;
+    if ((rc = ensure(c, b.recs, (size_t)n_slots * sizeof(TgtRec)))) return rc;
     if ((rc = ensure(c, b.nodes, (size_t)(n_inner > 0 ? n_inner : 1) * sizeof(BvhNodeT<DIM>)))) return rc;
     if ((rc = ensure(c, b.lvl, (size_t)(b.Lp > 1 ? b.Lp / 2 : 1) * 2 * DIM * 4))) return rc;
     if ((rc = ensure(c, b.wbox, (size_t)((cap + 63) / 64) * 2 * DIM * 4))) return rc;
@@ -251,7 +247,12 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
             int* t = perm; perm = perm2; perm2 = t;
         }
     }
-    hipLaunchKernelGGL(k_bvh_gather<DIM>, dim3((n_slots + 255) / 256), dim3(256), 0, c->stream, cp, perm, nv, n_slots, b.leaves.as<BvhLeafT<DIM>>());
+    {
+        const bool nrm = b.attrs && b.attrs->has_normals, col = b.attrs && b.attrs->has_colors;
+        hipLaunchKernelGGL(k_bvh_gather<DIM>, dim3((n_slots + 255) / 256), dim3(256), 0, c->stream, cp,
+                           nrm ? b.attrs->nx.as<float>() : nullptr, nrm ? b.attrs->ny.as<float>() : nullptr, nrm ? b.attrs->nz.as<float>() : nullptr,
+                           col ? b.attrs->rgba.as<uint32_t>() : nullptr, perm, nv, n_slots, b.leaves.as<BvhLeafT<DIM>>(), b.recs.as<TgtRec>());
+    }
     for (int d = depth - 1; d >= 0; d--) {
         const int count = 1 << d, first = count - 1;
         hipLaunchKernelGGL(k_bvh_nodes<DIM>, dim3((count + 255) / 256), dim3(256), 0, c->stream, b.leaves.as<BvhLeafT<DIM>>(), b.n_leaves, b.Lp, first, count,
@@ -279,12 +280,12 @@ CoordPtrs<6> target_coords6(const icp_ctx* c) {
     cp.c[3] = c->tgt.cr.as<float>(); cp.c[4] = c->tgt.cg.as<float>(); cp.c[5] = c->tgt.cb.as<float>(); return cp;
 }
 
-PostParams make_post_params(icp_ctx* c, const int* sel, int n) {
+PostParams make_post_params(icp_ctx* c, const Cloud& src, const int* sel, int n) {
     const icp_params& p = c->prm;
     PostParams pp;
-    pp.sx = c->src.x.as<float>(); pp.sy = c->src.y.as<float>(); pp.sz = c->src.z.as<float>();
-    pp.snx = c->src.nx.as<float>(); pp.sny = c->src.ny.as<float>(); pp.snz = c->src.nz.as<float>();
-    pp.srgba = c->src.rgba.as<uint32_t>(); pp.sel = sel; pp.n = n;
+    pp.sx = src.x.as<float>(); pp.sy = src.y.as<float>(); pp.sz = src.z.as<float>();
+    pp.snx = src.nx.as<float>(); pp.sny = src.ny.as<float>(); pp.snz = src.nz.as<float>();
+    pp.srgba = src.rgba.as<uint32_t>(); pp.sel = sel; pp.n = n;
     pp.tx = c->tgt.x.as<float>(); pp.ty = c->tgt.y.as<float>(); pp.tz = c->tgt.z.as<float>();
     pp.tnx = c->tgt.nx.as<float>(); pp.tny = c->tgt.ny.as<float>(); pp.tnz = c->tgt.nz.as<float>(); pp.trgba = c->tgt.rgba.as<uint32_t>();
     pp.ps = c->ps.as<PoseState>(); pp.matches = c->matches.as<icp_match_t>();
@@ -296,11 +297,11 @@ PostParams make_post_params(icp_ctx* c, const int* sel, int n) {
 // fuse != nullptr: run the post stage (weight / reject / accumulate) as the epilogue of the search; *fused_blocks receives the
 // number of block partials written.
 template <int DIM>
-int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnParams& kp, const int* order, int n, bool fuse, int* fused_blocks) {
+int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnParams& kp, const int* order, int n, const Cloud* fuse, int* fused_blocks) {
     int rc;
     if (!b.valid && (rc = build_bvh<DIM>(c, b, cp))) return rc;
     BvhViewT<DIM> bv; bv.leaves = b.leaves.as<BvhLeafT<DIM>>(); bv.nodes = b.nodes.as<BvhNodeT<DIM>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
-    bv.qnodes = b.qnodes.as<BvhQuadT<DIM>>(); bv.Lq = b.Lq;
+    bv.qnodes = b.qnodes.as<BvhQuadT<DIM>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>();
     const int nb = (n + BVH_THREADS - 1) / BVH_THREADS;
     const size_t stack_bytes = (size_t)(b.Lq > 0 ? b.Lq : 1) * BVH_THREADS * 8;
     if (kp.work_items) {
@@ -310,7 +311,7 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
         hipLaunchKernelGGL(k_knn_bvh<DIM>, dim3(nb), dim3(BVH_THREADS), stack_bytes, c->stream, kp, bv, (const int*)nullptr);
     } else if (fuse) {
         if ((rc = ensure(c, c->partials, (size_t)(nb > POST_BLOCKS ? nb : POST_BLOCKS) * NSUM * 8))) return rc;
-        const PostParams pp = make_post_params(c, kp.sel, n);
+        const PostParams pp = make_post_params(c, *fuse, kp.sel, n);
         const size_t red_bytes = (size_t)(BVH_THREADS / WAVE) * 34 * 17 * 8;      // the reduction reuses the (dead) traversal stacks
         hipLaunchKernelGGL(k_knn_bvh_post<DIM>, dim3(nb), dim3(BVH_THREADS), stack_bytes > red_bytes ? stack_bytes : red_bytes, c->stream, kp, bv, order, pp);
         *fused_blocks = nb;
@@ -360,7 +361,7 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr) {
             if ((rc = ensure(c, c->work_items, (size_t)q.n * 4))) return rc;
             kp.work_items = c->work_items.as<int>(); kp.work_n = c->work_counts.as<int>() + q.work_slot;
         }
-        const bool fuse = fused_blocks != nullptr && p.metric != ICP_METRIC_SYMMETRIC && !q.pretransformed && q.cl == &c->src;
+        const Cloud* fuse = (fused_blocks != nullptr && p.metric != ICP_METRIC_SYMMETRIC && !q.pretransformed) ? q.cl : nullptr;
         if (q.use_colors) return launch_bvh_query<6>(c, c->bvh6, target_coords6(c), kp, q.order, q.n, fuse, fused_blocks);
         return launch_bvh_query<3>(c, c->bvh, target_coords3(c), kp, q.order, q.n, fuse, fused_blocks);
     }
@@ -385,7 +386,7 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr) {
 }
 
 // Enqueue weight + reject + accumulate (+ symmetric second pass) + reduce/solve (no sync).
-int launch_post_and_solve(icp_ctx* c, const int* sel, int n, icp_iter_stats* d_stats, double* d_sums_out, int update_pose,
+int launch_post_and_solve(icp_ctx* c, const Cloud& src, const int* sel, int n, icp_iter_stats* d_stats, double* d_sums_out, int update_pose,
                           hipEvent_t ev_after_post, int fused_blocks = 0) {
     const icp_params& p = c->prm;
     int rc;
@@ -394,7 +395,7 @@ int launch_post_and_solve(icp_ctx* c, const int* sel, int n, icp_iter_stats* d_s
         if ((rc = ensure(c, c->totals, NSUM * 8 + 8))) return rc;
         HIPCK(c, hipMemsetAsync(c->totals.p, 0, NSUM * 8 + 8, c->stream));
     }
-    const PostParams pp = make_post_params(c, sel, n);
+    const PostParams pp = make_post_params(c, src, sel, n);
     int nb = (n + POST_THREADS - 1) / POST_THREADS; if (nb > POST_BLOCKS) nb = POST_BLOCKS; if (nb < 1) nb = 1;
     if (fused_blocks) nb = fused_blocks;                    // the matcher already wrote the block partials
     else hipLaunchKernelGGL(k_post, dim3(nb), dim3(POST_THREADS), 0, c->stream, pp);
@@ -439,13 +440,16 @@ int check_ready(icp_ctx* c, bool need_source, bool full_pipeline) {
 int get_level(icp_ctx* c, int factor, const int** d_idx, int* n_out, const int** d_order) {
     auto it = c->levels.find(factor);
     if (it == c->levels.end()) {
-        std::vector<int> idx;
-        idx.reserve(c->src.n / factor + 1);
-        for (int i = 0; i < c->src.n; i += factor) if (c->src_valid[i]) idx.push_back(i);
-        Level lv; lv.n = (int)idx.size();
+        Level lv;
         int rc;
-        if ((rc = ensure(c, lv.idx, (size_t)(lv.n > 0 ? lv.n : 1) * 4))) return rc;
-        if (lv.n > 0) HIPCK(c, hipMemcpy(lv.idx.p, idx.data(), (size_t)lv.n * 4, hipMemcpyHostToDevice));
+        if (factor > 0) {
+            std::vector<int> idx;
+            idx.reserve(c->src.n / factor + 1);
+            for (int i = 0; i < c->src.n; i += factor) if (c->src_valid[i]) idx.push_back(i);
+            lv.n = (int)idx.size();
+            if ((rc = ensure(c, lv.idx, (size_t)(lv.n > 0 ? lv.n : 1) * 4))) return rc;
+            if (lv.n > 0) HIPCK(c, hipMemcpy(lv.idx.p, idx.data(), (size_t)lv.n * 4, hipMemcpyHostToDevice));
+        } else lv.n = c->src.n;                                   // factor 0: every point, no index list
         it = c->levels.emplace(factor, lv).first;
     }
     *d_idx = it->second.idx.as<int>(); *n_out = it->second.n;
@@ -456,6 +460,47 @@ int get_level(icp_ctx* c, int factor, const int** d_idx, int* n_out, const int**
             *d_order = it->second.order.as<int>();
         }
     }
+    return ICP_OK;
+}
+
+// Morton order of the whole resident source for the stage-level entry points (results stay in source order); nullptr
+// when the BVH matcher is not in use.
+int get_full_order(icp_ctx* c, const int** out) {
+    *out = nullptr;
+    const icp_params& p = c->prm;
+    if (!(p.matching == ICP_MATCH_KNN && p.knn_backend == ICP_KNN_LBVH) || c->src.n <= 0) return ICP_OK;
+    const int* idx; int n;
+    return get_level(c, 0, &idx, &n, out);
+}
+
+// The level's points physically permuted into Morton order (built once per icp_set_source and level).
+int get_sorted_level(icp_ctx* c, int factor, const Cloud** cloud, int* n_out) {
+    const int* d_idx; const int* d_order; int n, rc;
+    if ((rc = get_level(c, factor, &d_idx, &n, &d_order))) return rc;
+    Level& lv = c->levels[factor];
+    *n_out = n;
+    if (!lv.sorted_valid && n > 0) {
+        if ((rc = ensure(c, lv.sorted_idx, (size_t)n * 4))) return rc;
+        const dim3 g((n + 255) / 256), b(256);
+        hipLaunchKernelGGL(k_compose_idx, g, b, 0, c->stream, d_idx, d_order, n, lv.sorted_idx.as<int>());
+        const int* si = lv.sorted_idx.as<int>();
+        Cloud& d = lv.sorted; const Cloud& s = c->src;
+        d.n = n; d.npad = n; d.has_normals = s.has_normals; d.has_colors = s.has_colors;
+        DevBuf* dst[9] = {&d.x, &d.y, &d.z, &d.nx, &d.ny, &d.nz, &d.cr, &d.cg, &d.cb};
+        const DevBuf* srcp[9] = {&s.x, &s.y, &s.z, &s.nx, &s.ny, &s.nz, &s.cr, &s.cg, &s.cb};
+        for (int k = 0; k < 9; k++) {
+            if (!srcp[k]->p) continue;
+            if ((rc = ensure(c, *dst[k], (size_t)n * 4))) return rc;
+            hipLaunchKernelGGL(k_gather_f32, g, b, 0, c->stream, srcp[k]->as<float>(), si, n, dst[k]->as<float>());
+        }
+        if (s.rgba.p) {
+            if ((rc = ensure(c, d.rgba, (size_t)n * 4))) return rc;
+            hipLaunchKernelGGL(k_gather_u32, g, b, 0, c->stream, s.rgba.as<uint32_t>(), si, n, d.rgba.as<uint32_t>());
+        }
+        HIPCK(c, hipGetLastError());
+        lv.sorted_valid = true;
+    }
+    *cloud = &lv.sorted;
     return ICP_OK;
 }
 
@@ -518,10 +563,10 @@ int icp_ctx_destroy(icp_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release(c->tgt); release(c->src); release(c->qry); release(c->conv_src); release(c->conv_ref);
     release(c->nrm_cloud);
-    for (Bvh* b : {&c->bvh, &c->bvh6, &c->nrm_bvh}) { release(b->qnodes); }
+    for (Bvh* b : {&c->bvh, &c->bvh6, &c->nrm_bvh}) { release(b->qnodes); release(b->recs); }
     for (Bvh* b : {&c->bvh6, &c->nrm_bvh}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
-    release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->order_full); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
-    for (auto& kv : c->levels) { release(kv.second.idx); release(kv.second.order); }
+    release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
+    for (auto& kv : c->levels) release(kv.second);
     release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->work_items); release(c->work_counts); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -557,6 +602,7 @@ int icp_set_target(icp_ctx* c, const float* xyz, const float* normals, const uin
     }
     b.n_valid = (int)b.finite_idx.size();
     c->bvh6.finite_idx = b.finite_idx; c->bvh6.n_valid = b.n_valid;
+    b.attrs = &c->tgt; c->bvh6.attrs = &c->tgt;
     if (c->prm.knn_backend == ICP_KNN_LBVH && c->prm.matching == ICP_MATCH_KNN) {                         // buildIndex; otherwise built on first use
         if (c->prm.color_icp && rgba) return build_bvh<6>(c, c->bvh6, target_coords6(c));
         return build_bvh<3>(c, b, target_coords3(c));
@@ -577,9 +623,8 @@ int icp_set_source(icp_ctx* c, const float* xyz, const float* normals, const uin
         if (ok && normals) ok = std::isfinite(normals[(size_t)i * 3]) && std::isfinite(normals[(size_t)i * 3 + 1]) && std::isfinite(normals[(size_t)i * 3 + 2]);
         c->src_valid[i] = ok ? 1 : 0;
     }
-    for (auto& kv : c->levels) { release(kv.second.idx); release(kv.second.order); }
+    for (auto& kv : c->levels) release(kv.second);
     c->levels.clear();
-    c->order_full_valid = false;
     return ICP_OK;
 }
 
@@ -628,7 +673,7 @@ int icp_correspond(icp_ctx* c, const float pose[16], icp_match_t* out, double* s
     QuerySet q{&c->src, nullptr, c->src.n, 0, c->prm.color_icp != 0 && c->prm.matching == ICP_MATCH_KNN, false, full_order};
     if ((rc = launch_match(c, q))) return rc;
     if ((rc = ensure(c, c->sums, NSUM * 8))) return rc;
-    if ((rc = launch_post_and_solve(c, nullptr, q.n, nullptr, c->sums.as<double>(), 0, nullptr))) return rc;
+    if ((rc = launch_post_and_solve(c, c->src, nullptr, q.n, nullptr, c->sums.as<double>(), 0, nullptr))) return rc;
     double hs[NSUM];
     if (out) HIPCK(c, hipMemcpyAsync(out, c->matches.p, (size_t)q.n * sizeof(icp_match_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(hs, c->sums.p, NSUM * 8, hipMemcpyDeviceToHost, c->stream));
@@ -686,10 +731,12 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     // resolve selections up front (uploads) so the loop itself is launch-only
     std::vector<const int*> sels(iters, nullptr); std::vector<int> ns(iters, c->src.n);
     std::vector<const int*> orders(iters, nullptr);
-    const bool want_order = p.matching == ICP_MATCH_KNN && p.knn_backend == ICP_KNN_LBVH;
+    std::vector<const Cloud*> clouds(iters, &c->src);
+    // BVH matcher without resampling: every level is a physical, Morton-sorted copy -> no index lists in the loop at all
+    const bool sorted_levels = p.matching == ICP_MATCH_KNN && p.knn_backend == ICP_KNN_LBVH && !(!single && p.selection == 1);
     for (int i = 0; i < iters; i++) {
-        if (factors[i] > 0) { if ((rc = get_level(c, factors[i], &sels[i], &ns[i], want_order ? &orders[i] : nullptr))) return rc; }
-        else if (want_order) { if ((rc = get_full_order(c, &orders[i]))) return rc; }
+        if (sorted_levels) { if ((rc = get_sorted_level(c, factors[i], &clouds[i], &ns[i]))) return rc; }
+        else if (factors[i] > 0) { if ((rc = get_level(c, factors[i], &sels[i], &ns[i], nullptr))) return rc; }
     }
     if (!single && p.selection == 1) {
         // RANDOM_SAMPLING (ICPOptimizer.h:549-550: resample at the start of every iteration, over the current level's cloud).
@@ -721,6 +768,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     const bool fontana = (p.record_rmse & 2) && c->conv_n > 0;
     if (rmse) { if ((rc = ensure(c, c->rmse_partials, 256 * 2 * 8))) return rc; }
     const bool ev = c->stage_events;
+    std::vector<char> post_event((size_t)iters, 0);
     if (p.knn_backend == ICP_KNN_LBVH && p.matching == ICP_MATCH_KNN && p.knn_incremental) {     // work-list counters, one per iteration
         if ((rc = ensure(c, c->work_counts, (size_t)iters * 4))) return rc;
         HIPCK(c, hipMemsetAsync(c->work_counts.p, 0, (size_t)iters * 4, c->stream));
@@ -731,15 +779,16 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
         if (ns[i] > 0) {
             // seed the search with the previous iteration's neighbours when it matched the same queries (same level)
             const bool seed = i > 0 && factors[i] == factors[i - 1] && ns[i - 1] > 0 && p.selection == 0;
-            QuerySet q{&c->src, sels[i], ns[i], 0, p.color_icp != 0 && p.matching == ICP_MATCH_KNN, seed, orders[i]};
+            QuerySet q{clouds[i], sels[i], ns[i], 0, p.color_icp != 0 && p.matching == ICP_MATCH_KNN, seed, orders[i]};
             q.work_slot = i;
             int fused = 0;
             if ((rc = launch_match(c, q, c->fuse_post ? &fused : nullptr))) return rc;
             if (ev) HIPCK(c, hipEventRecord(c->events[1 + 3 * i], c->stream));
-            if ((rc = launch_post_and_solve(c, sels[i], ns[i], d_st, nullptr, 1, ev ? c->events[2 + 3 * i] : nullptr, fused))) return rc;
+            // fused epilogue: there is no separate post stage to bracket (an event costs ~4 us of stream time)
+            if ((rc = launch_post_and_solve(c, *clouds[i], sels[i], ns[i], d_st, nullptr, 1, (ev && !fused) ? c->events[2 + 3 * i] : nullptr, fused))) return rc;
+            post_event[i] = ev && !fused;
         } else if (ev) {
             HIPCK(c, hipEventRecord(c->events[1 + 3 * i], c->stream));
-            HIPCK(c, hipEventRecord(c->events[2 + 3 * i], c->stream));
         }
         if (rmse) {
             hipLaunchKernelGGL(k_rmse_partial, dim3(256), dim3(256), 0, c->stream, c->conv_src.x.as<float>(), c->conv_src.y.as<float>(), c->conv_src.z.as<float>(),
@@ -768,8 +817,8 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     for (int i = 0; ev && i < iters; i++) {
         float a = 0, b = 0, d = 0;
         HIPCK(c, hipEventElapsedTime(&a, c->events[3 * i], c->events[1 + 3 * i]));
-        HIPCK(c, hipEventElapsedTime(&b, c->events[1 + 3 * i], c->events[2 + 3 * i]));
-        HIPCK(c, hipEventElapsedTime(&d, c->events[2 + 3 * i], c->events[3 + 3 * i]));
+        if (post_event[i]) HIPCK(c, hipEventElapsedTime(&b, c->events[1 + 3 * i], c->events[2 + 3 * i]));
+        HIPCK(c, hipEventElapsedTime(&d, c->events[post_event[i] ? 2 + 3 * i : 1 + 3 * i], c->events[3 + 3 * i]));
         t.match_ms += a; t.weight_reject_build_ms += b; t.solve_ms += d;
         if (c->trace) fprintf(stderr, "[icp_hip] it %2d  n %d  match %.4f  post %.4f  solve %.4f ms\n", i, ns[i], a, b, d);
     }
@@ -899,6 +948,7 @@ int icp_estimate_normals(icp_ctx* c, const float* xyz, int32_t n, int32_t k, con
     CoordPtrs<3> cp; cp.c[0] = cl.x.as<float>(); cp.c[1] = cl.y.as<float>(); cp.c[2] = cl.z.as<float>();
     if ((rc = build_bvh<3>(c, b, cp))) return rc;
     BvhViewT<3> bv; bv.leaves = b.leaves.as<BvhLeafT<3>>(); bv.nodes = b.nodes.as<BvhNodeT<3>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
+    bv.qnodes = b.qnodes.as<BvhQuadT<3>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>();
     int depth = 0; while ((1 << depth) < b.Lp) depth++;
     if ((rc = ensure(c, c->staging, (size_t)n * 16))) return rc;
     float* d_n = c->staging.as<float>(); float* d_c = d_n + (size_t)n * 3;
