@@ -234,6 +234,8 @@ def main():
     launches = max(acc["iterations"], 1)
     knn_ms = acc["match_ms"] / launches
     alg_bytes = 12 * n_src + 12 * n_tgt + 8 * n_src                    # read src xyz + tgt xyz, write Match
+    if knn_ms <= 0.0:                                                   # ICP_HIP_STAGE_EVENTS=0: no per-stage events, no kernel duration
+        knn_ms = float("nan")
     achieved = alg_bytes / (knn_ms * 1e-3) / 1e9
     pairs = float(n_src) * float(n_tgt)
     flops = pairs * 8.0                                                 # 3 sub + 3 mul + 2 add per pair (no FMA: bit-exact contract)
@@ -265,7 +267,7 @@ def main():
         "ms_per_iteration": elapsed / (args.steps * args.iterations) * 1e3,
         "stage_ms_per_iteration": {"match": acc["match_ms"] / launches, "weight_reject_build": acc["weight_reject_build_ms"] / launches,
                                    "solve": acc["solve_ms"] / launches},
-        "roofline": {"kernel": "k_knn_%s" % args.knn, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"kernel": "k_knn_bvh_post<3> (exact BVH 1-NN + weight/reject/accumulate epilogue)" if args.knn == "lbvh" else "k_knn_brute<3>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": knn_ms},
         "valu_roofline": {"pair_evals_per_s": pairs / (knn_ms * 1e-3) if args.knn == "brute" else None,

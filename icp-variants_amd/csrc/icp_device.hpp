@@ -220,6 +220,9 @@ __global__ void k_knn_finalize(const unsigned long long* __restrict__ best64, in
 //           monotonicity of IEEE rounding fl(d2(point)) >= fl(lb) for every point in the box (a 1e-5 relative margin is
 //           kept on top).  Equal distances resolve to the lowest original index, exactly like the strict-< scan
 //           (NearestNeighbor.h:87).
+#ifndef ICP_PREFETCH_PATH
+#define ICP_PREFETCH_PATH 1
+#endif
 constexpr int BVH_LEAF = 8;
 constexpr int BVH_THREADS = 128;
 
@@ -661,7 +664,7 @@ __device__ __forceinline__ void knn_bvh_query(const KnnParams& kp, const BvhView
             for (int q = 0; q < DIM; q++) { p2[q].x = p[q]; p2[q].y = p[q]; }
             float best2 = FLT_MAX, minlb = FLT_MAX;
             unsigned int touched = 0u;
-            if (bpos >= 0) touched = quad_prefetch_path<DIM>(bv, bpos >> 3);
+            if (ICP_PREFETCH_PATH && bpos >= 0) touched = quad_prefetch_path<DIM>(bv, bpos >> 3);
             QuadState st; st.L = 0; st.idx = 0; st.pending = 0ull; st.alive = true;
             quad_run<DIM>(bv, p2, st, best, bi, bpos, best2, minlb, lbq, tid, BVH_THREADS);
             asm volatile("" ::"v"(touched));

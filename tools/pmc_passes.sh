@@ -2,7 +2,7 @@
 # PMC passes for the ICP kernels (one rocprofv3 run per counter group; --kernel-trace only, as the guide prescribes).
 # usage: tools/pmc_passes.sh <outdir> <backend> <iters>
 OUT=$1; BACKEND=${2:-lbvh}; ITERS=${3:-5}
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p $OUT
 i=0
 for P in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" \
          "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_LEVEL_VMEM SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH" \
