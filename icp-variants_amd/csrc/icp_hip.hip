@@ -64,7 +64,8 @@ struct icp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
-    bool stage_events = true;            // per-stage HIP events inside icp_run (ICP_HIP_STAGE_EVENTS=0: only whole-run events)
+    int stage_timing = 1;                // icp_set_stage_timing: 0 none, 1 every iteration, N > 1 every Nth iteration (scaled)
+    unsigned timing_phase = 0;           // rotates the sampled iterations from run to run
     bool trace = false;                  // ICP_HIP_TRACE=1: per-iteration stage times on stderr
     bool two_pass = false;               // incremental k-NN as verify pass + packed tree-walk pass (ICP_HIP_TWO_PASS=1; measured slower: walk latency is exposed)
     bool fuse_post = true;               // BVH matcher runs weight / reject / accumulate as its epilogue (ICP_HIP_FUSE_POST=0 disables)
@@ -542,7 +543,7 @@ int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out) {
     { const char* e = getenv("ICP_HIP_FUSE_POST"); if (e && e[0] == '0') c->fuse_post = false; }
     { const char* e = getenv("ICP_HIP_TRACE"); if (e && e[0] == '1') c->trace = true; }
     { const char* e = getenv("ICP_HIP_TWO_PASS"); if (e && e[0] == '1') c->two_pass = true; }
-    { const char* e = getenv("ICP_HIP_STAGE_EVENTS"); if (e && e[0] == '0') c->stage_events = false; }
+    { const char* e = getenv("ICP_HIP_STAGE_EVENTS"); if (e && e[0] >= '0' && e[0] <= '9') c->stage_timing = atoi(e); }
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->owns_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return ICP_ERR_HIP; }
@@ -727,7 +728,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     if ((rc = write_pose(c, pose_inout))) return rc;
     if ((rc = ensure(c, c->stats, (size_t)iters * sizeof(icp_iter_stats)))) return rc;
     HIPCK(c, hipMemsetAsync(c->stats.p, 0, (size_t)iters * sizeof(icp_iter_stats), c->stream));
-    if ((rc = ensure_events(c, (size_t)iters * 3 + 1))) return rc;
+    if ((rc = ensure_events(c, (size_t)iters * 4 + 2))) return rc;
     // resolve selections up front (uploads) so the loop itself is launch-only
     std::vector<const int*> sels(iters, nullptr); std::vector<int> ns(iters, c->src.n);
     std::vector<const int*> orders(iters, nullptr);
@@ -767,8 +768,15 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     const bool rmse = (p.record_rmse & 1) && c->conv_n > 0;
     const bool fontana = (p.record_rmse & 2) && c->conv_n > 0;
     if (rmse) { if ((rc = ensure(c, c->rmse_partials, 256 * 2 * 8))) return rc; }
-    const bool ev = c->stage_events;
-    std::vector<char> post_event((size_t)iters, 0);
+    // Stage timing (TimeMeasure.h:20-26).  A HIP event costs ~4 us of stream time, two to three per iteration are ~10 % of a
+    // 0.07 ms iteration: mode N > 1 brackets only every Nth iteration (offset rotating from run to run) and scales the sums.
+    // Event slots: 4 per iteration (start, after match, after post, end) + run start / run end.
+    const int tmode = c->stage_timing;
+    std::vector<char> sampled((size_t)iters, 0), post_event((size_t)iters, 0);
+    for (int i = 0; i < iters; i++) sampled[i] = tmode == 1 || (tmode > 1 && (i + (int)(c->timing_phase % (unsigned)tmode)) % tmode == 0);
+    c->timing_phase++;
+    auto E = [&](int i, int k) { return c->events[(size_t)2 + 4 * i + k]; };
+    auto start_event = [&](int i) { return (i > 0 && sampled[i - 1]) ? E(i - 1, 3) : E(i, 0); };
     if (p.knn_backend == ICP_KNN_LBVH && p.matching == ICP_MATCH_KNN && p.knn_incremental) {     // work-list counters, one per iteration
         if ((rc = ensure(c, c->work_counts, (size_t)iters * 4))) return rc;
         HIPCK(c, hipMemsetAsync(c->work_counts.p, 0, (size_t)iters * 4, c->stream));
@@ -776,6 +784,8 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     HIPCK(c, hipEventRecord(c->events[0], c->stream));
     for (int i = 0; i < iters; i++) {
         icp_iter_stats* d_st = c->stats.as<icp_iter_stats>() + i;
+        const bool ev = sampled[i] != 0;
+        if (ev && !(i > 0 && sampled[i - 1])) HIPCK(c, hipEventRecord(E(i, 0), c->stream));
         if (ns[i] > 0) {
             // seed the search with the previous iteration's neighbours when it matched the same queries (same level)
             const bool seed = i > 0 && factors[i] == factors[i - 1] && ns[i - 1] > 0 && p.selection == 0;
@@ -783,12 +793,12 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
             q.work_slot = i;
             int fused = 0;
             if ((rc = launch_match(c, q, c->fuse_post ? &fused : nullptr))) return rc;
-            if (ev) HIPCK(c, hipEventRecord(c->events[1 + 3 * i], c->stream));
-            // fused epilogue: there is no separate post stage to bracket (an event costs ~4 us of stream time)
-            if ((rc = launch_post_and_solve(c, *clouds[i], sels[i], ns[i], d_st, nullptr, 1, (ev && !fused) ? c->events[2 + 3 * i] : nullptr, fused))) return rc;
+            if (ev) HIPCK(c, hipEventRecord(E(i, 1), c->stream));
+            // fused epilogue: there is no separate post stage to bracket
+            if ((rc = launch_post_and_solve(c, *clouds[i], sels[i], ns[i], d_st, nullptr, 1, (ev && !fused) ? E(i, 2) : nullptr, fused))) return rc;
             post_event[i] = ev && !fused;
         } else if (ev) {
-            HIPCK(c, hipEventRecord(c->events[1 + 3 * i], c->stream));
+            HIPCK(c, hipEventRecord(E(i, 1), c->stream));
         }
         if (rmse) {
             hipLaunchKernelGGL(k_rmse_partial, dim3(256), dim3(256), 0, c->stream, c->conv_src.x.as<float>(), c->conv_src.y.as<float>(), c->conv_src.z.as<float>(),
@@ -796,8 +806,9 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
             hipLaunchKernelGGL(k_rmse_finish, dim3(1), dim3(64), 0, c->stream, c->rmse_partials.as<double>(), 256, &d_st->rmse);
         }
         if (fontana && (rc = enqueue_fontana(c, &d_st->benchmark_error))) return rc;
-        if (ev || i == iters - 1) HIPCK(c, hipEventRecord(c->events[3 + 3 * i], c->stream));
+        if (ev) HIPCK(c, hipEventRecord(E(i, 3), c->stream));
     }
+    HIPCK(c, hipEventRecord(c->events[1], c->stream));
     std::vector<icp_iter_stats> hs((size_t)iters);
     PoseState hp;
     HIPCK(c, hipMemcpyAsync(hs.data(), c->stats.p, (size_t)iters * sizeof(icp_iter_stats), hipMemcpyDeviceToHost, c->stream));
@@ -814,14 +825,22 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     }
     if (n_run) *n_run = iters;
     icp_timing& t = c->timing; memset(&t, 0, sizeof(t)); t.iterations = iters;
-    for (int i = 0; ev && i < iters; i++) {
+    int n_sampled = 0;
+    for (int i = 0; i < iters; i++) {
+        if (!sampled[i]) continue;
+        n_sampled++;
         float a = 0, b = 0, d = 0;
-        HIPCK(c, hipEventElapsedTime(&a, c->events[3 * i], c->events[1 + 3 * i]));
-        if (post_event[i]) HIPCK(c, hipEventElapsedTime(&b, c->events[1 + 3 * i], c->events[2 + 3 * i]));
-        HIPCK(c, hipEventElapsedTime(&d, c->events[post_event[i] ? 2 + 3 * i : 1 + 3 * i], c->events[3 + 3 * i]));
+        HIPCK(c, hipEventElapsedTime(&a, start_event(i), E(i, 1)));
+        if (post_event[i]) HIPCK(c, hipEventElapsedTime(&b, E(i, 1), E(i, 2)));
+        HIPCK(c, hipEventElapsedTime(&d, post_event[i] ? E(i, 2) : E(i, 1), E(i, 3)));
         t.match_ms += a; t.weight_reject_build_ms += b; t.solve_ms += d;
         if (c->trace) fprintf(stderr, "[icp_hip] it %2d  n %d  match %.4f  post %.4f  solve %.4f ms\n", i, ns[i], a, b, d);
     }
+    if (n_sampled > 0 && n_sampled < iters) {             // sampled: scale to the whole run
+        const double f = (double)iters / n_sampled;
+        t.match_ms *= f; t.weight_reject_build_ms *= f; t.solve_ms *= f;
+    }
+    t.sampled_iterations = n_sampled;
     if (c->trace && c->work_counts.p && c->two_pass) {
         std::vector<int> wc((size_t)iters);
         HIPCK(c, hipMemcpy(wc.data(), c->work_counts.p, (size_t)iters * 4, hipMemcpyDeviceToHost));
@@ -829,7 +848,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
         for (int i = 0; i < iters; i++) fprintf(stderr, " %d", wc[i]);
         fprintf(stderr, "\n");
     }
-    float tot = 0; HIPCK(c, hipEventElapsedTime(&tot, c->events[0], c->events[3 * iters])); t.total_ms = tot;
+    float tot = 0; HIPCK(c, hipEventElapsedTime(&tot, c->events[0], c->events[1])); t.total_ms = tot;
     if (status != ICP_OK) c->err = "no valid correspondences in at least one iteration (reference would hang in ASSERT)";
     return status;
 }
@@ -843,6 +862,12 @@ int icp_iterate(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats) {
 int icp_run(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int32_t max_stats, int32_t* n_iterations_run) {
     if (!c || !pose_inout) { if (c) c->err = "icp_run: bad argument"; return ICP_ERR_INVALID_ARG; }
     return run_loop(c, pose_inout, stats, stats ? max_stats : 0, n_iterations_run, false);
+}
+
+int icp_set_stage_timing(icp_ctx* c, int32_t every_nth) {
+    if (!c || every_nth < 0) { if (c) c->err = "icp_set_stage_timing: bad argument"; return ICP_ERR_INVALID_ARG; }
+    c->stage_timing = every_nth;
+    return ICP_OK;
 }
 
 int icp_get_timing(const icp_ctx* c, icp_timing* out) { if (!c || !out) return ICP_ERR_INVALID_ARG; *out = c->timing; return ICP_OK; }

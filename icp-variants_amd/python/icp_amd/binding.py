@@ -44,13 +44,13 @@ class IcpIterStats(C.Structure):
 
 class IcpTiming(C.Structure):
     _fields_ = [("match_ms", C.c_double), ("weight_reject_build_ms", C.c_double), ("solve_ms", C.c_double),
-                ("total_ms", C.c_double), ("iterations", C.c_int32)]
+                ("total_ms", C.c_double), ("iterations", C.c_int32), ("sampled_iterations", C.c_int32)]
 
 
 # every symbol include/icp_hip.h declares (tests check the library exports all of them)
 EXPORTS = ["icp_ctx_create", "icp_ctx_create_on_stream", "icp_ctx_destroy", "icp_last_error", "icp_params_default",
            "icp_set_params", "icp_get_params", "icp_set_target", "icp_set_source", "icp_query_matches", "icp_match",
-           "icp_correspond", "icp_iterate", "icp_run", "icp_get_timing", "icp_set_convergence_reference", "icp_rmse", "icp_benchmark_error",
+           "icp_correspond", "icp_iterate", "icp_run", "icp_get_timing", "icp_set_stage_timing", "icp_set_convergence_reference", "icp_rmse", "icp_benchmark_error",
            "icp_transform_points", "icp_transform_normals", "icp_version", "icp_schedule", "icp_select_hash", "icp_backproject_depth", "icp_estimate_normals"]
 
 _lib = None
@@ -188,7 +188,11 @@ class Context:
         t = IcpTiming()
         self._ck(self.lib.icp_get_timing(self.h, C.byref(t)))
         return dict(match_ms=t.match_ms, weight_reject_build_ms=t.weight_reject_build_ms, solve_ms=t.solve_ms,
-                    total_ms=t.total_ms, iterations=t.iterations)
+                    total_ms=t.total_ms, iterations=t.iterations, sampled_iterations=t.sampled_iterations)
+
+    def set_stage_timing(self, every_nth):
+        """0: whole-run time only; 1: HIP events around every iteration's stages (default); N > 1: every Nth iteration, scaled."""
+        self._ck(self.lib.icp_set_stage_timing(self.h, C.c_int32(int(every_nth))))
 
     def set_convergence_reference(self, src_xyz, ref_xyz):
         s, r = _f32(src_xyz), _f32(ref_xyz)

@@ -92,6 +92,7 @@ typedef struct icp_timing {
     double solve_ms;         /* reduction + linear solve + pose composition    */
     double total_ms;         /* convergenceTime                                 */
     int32_t iterations;
+    int32_t sampled_iterations;   /* iterations that were bracketed by events (== iterations unless icp_set_stage_timing(N > 1)) */
 } icp_timing;
 
 /* -------- context -------- */
@@ -135,6 +136,10 @@ int icp_correspond(icp_ctx* ctx, const float pose[16], icp_match_t* out, double*
 int icp_iterate(icp_ctx* ctx, float pose_inout[16], icp_iter_stats* stats);
 int icp_run(icp_ctx* ctx, float pose_inout[16], icp_iter_stats* stats, int32_t max_stats, int32_t* n_iterations_run);
 int icp_get_timing(const icp_ctx* ctx, icp_timing* out);
+/* How icp_run fills the stage breakdown: 0 = whole-run time only, 1 = every iteration bracketed by HIP events (default;
+ * what TimeMeasure does), N > 1 = every Nth iteration (rotating offset), stage sums scaled by iterations / sampled.
+ * A HIP event costs about 4 us of stream time, i.e. mode 1 is ~10 % of a 0.07 ms iteration. */
+int icp_set_stage_timing(icp_ctx* ctx, int32_t every_nth);
 /* The iteration schedule icp_run will execute (pure host logic, no device needed): one decimation factor per
  * iteration, 0 = full cloud without selection.  ICPOptimizer.h:503-516,540,634-655 / PointCloud.h:325-343. */
 int icp_schedule(const icp_params* p, int32_t n_src, int32_t* factors_out, int32_t max_out, int32_t* count_out);

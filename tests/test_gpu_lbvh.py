@@ -164,3 +164,23 @@ def test_incremental_search_is_bit_identical_to_full_search(gpu_ctx_factory, bun
     assert len(out[0]) == len(out[1])
     for a, b in zip(*out):
         assert a["n_valid"] == b["n_valid"] and np.array_equal(a["pose"], b["pose"])
+
+
+def test_stage_timing_modes_do_not_change_the_result(gpu_ctx_factory, bunny):
+    """icp_set_stage_timing: 0 (whole run only), 1 (every iteration, TimeMeasure-like), N (every Nth, scaled) -- same poses."""
+    poses, timings = [], []
+    for mode in (1, 0, 4):
+        c = gpu_ctx_factory()
+        c.params.metric = 1; c.params.max_distance = 0.0003; c.params.n_iterations = 12; c.params.knn_backend = LBVH; c.push_params()
+        c.set_target(bunny["tgt_pts"], bunny["tgt_nrm"]); c.set_source(bunny["src_pts"], bunny["src_nrm"])
+        c.set_stage_timing(mode)
+        for _ in range(2):                                  # the sampled offset rotates from run to run
+            pose, recs, rc = c.run(np.eye(4))
+        assert rc == 0
+        poses.append(pose); timings.append(c.timing())
+    assert np.array_equal(poses[0], poses[1]) and np.array_equal(poses[0], poses[2])
+    t1, t0, t4 = timings
+    assert t1["iterations"] == 12 and t1["sampled_iterations"] == 12 and t1["match_ms"] > 0 and t1["solve_ms"] > 0
+    assert t0["sampled_iterations"] == 0 and t0["match_ms"] == 0 and t0["total_ms"] > 0
+    assert t4["sampled_iterations"] == 3 and t4["match_ms"] > 0 and t4["total_ms"] > 0
+    assert t4["match_ms"] + t4["solve_ms"] < 3 * t4["total_ms"]          # scaled sums stay in the right ballpark
