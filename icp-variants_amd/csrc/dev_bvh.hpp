@@ -1,0 +1,532 @@
+// dev_bvh.hpp -- exact kd-ordered BVH: build kernels, 4-wide nodes, walk, k_knn_bvh / k_knn_verify.
+// Part of icp_device.hpp (included from there, inside namespace icpdev); see that file for the build contract.
+// ------------------------------------------------------------------------------------------------
+// Exact kd-ordered BVH 1-NN: the index the reference builds once per pair (NearestNeighbor.h:122-141 / :209-232, a FLANN
+// kd-tree over xyz or over the 6-D xyz+rgb/255 features) rebuilt on the device as a balanced kd-tree in implicit heap
+// layout, queried with the SAME fp32 distance and the same lexicographic (d2, lowest index) argmin as k_knn_brute<DIM> --
+// bit-identical results, O(log M) nodes per query instead of M distance evaluations.  DIM = 3 or 6.
+//   build : level by level, every node's points are sorted along the widest axis of the node's bounding box
+//           (one rocPRIM sort per level over keys (node id << 32 | ordered coordinate bits)); the implicit node k
+//           covers a fixed, leaf-aligned slice of the array, so the count-balanced median split is simply
+//           "first half / second half".  Leaves hold BVH_LEAF points SoA + original indices; node records hold BOTH
+//           child boxes, pair-interleaved for packed-f32 math, and are filled bottom-up.
+//   query : one lane = one query, depth-first "near child first".  A node is skipped only if its box lower bound
+//           exceeds the running best; the bound uses the same operation sequence as the point distance, so by
+//           monotonicity of IEEE rounding fl(d2(point)) >= fl(lb) for every point in the box (a 1e-5 relative margin is
+//           kept on top).  Equal distances resolve to the lowest original index, exactly like the strict-< scan
+//           (NearestNeighbor.h:87).
+#ifndef ICP_PREFETCH_PATH
+#define ICP_PREFETCH_PATH 1
+#endif
+constexpr int BVH_LEAF = 8;
+constexpr int BVH_THREADS = 128;
+
+template <int DIM> struct BvhNodeT { float lo[DIM][2]; float hi[DIM][2]; float pad[DIM == 3 ? 4 : 8]; };   // 64 B / 128 B
+template <int DIM> struct BvhLeafT { float c[DIM][BVH_LEAF]; int idx[BVH_LEAF]; float pad[DIM == 3 ? 0 : 8]; };   // 128 B / 256 B
+template <> struct BvhLeafT<3> { float c[3][BVH_LEAF]; int idx[BVH_LEAF]; };
+typedef BvhNodeT<3> BvhNode;
+typedef BvhLeafT<3> BvhLeaf;
+
+// 4-wide node of the same tree with two binary levels collapsed: the boxes of the four grandchildren, SoA per axis (two
+// packed-f32 pairs each).  96 B / 192 B.  Half the dependent loads per query of the binary walk -- the search is bound by
+// the latency of that chain, not by bytes or flops.  128 B / 256 B.
+template <int DIM> struct BvhQuadT { float lo[DIM][4]; float hi[DIM][4]; float pad[DIM == 3 ? 8 : 16]; };   // padded to one / two 128-byte lines
+
+// Everything the loop needs about a matched target point in ONE 32-byte record, stored in kd (leaf) order -- position
+// pos = 8 * leaf + slot.  Neighbouring (Morton-sorted) queries match neighbouring positions, so the gather of the
+// correspondence (point, normal, colour) is one sector per query instead of seven scattered planes.
+struct TgtRec { float x, y, z; int idx; float nx, ny, nz; uint32_t rgba; };
+
+template <int DIM> struct CoordPtrs { const float* c[DIM]; };
+
+template <int DIM> struct BvhViewT {
+    const BvhLeafT<DIM>* leaves;  // [max(n_leaves,1)] kd-ordered points, 8 per leaf; pads are +inf with index -1
+    const BvhNodeT<DIM>* nodes;   // [Lp - 1] internal nodes in heap order (node k: children 2k+1, 2k+2; leaves start at Lp-1)
+    const TgtRec* recs;           // [8 * max(n_leaves,1)] point + normal + colour + original index by position
+    const BvhQuadT<DIM>* qnodes;  // [(4^Lq - 1) / 3] 4-wide nodes, level l at offset (4^l - 1) / 3; the children of level Lq - 1 are the leaves
+    int Lq;                       // 4-wide levels = ceil(log2(Lp) / 2)  (an odd binary depth gets a virtual root with one empty half)
+    int n_valid;                  // finite target points in the tree
+    int Lp;                       // leaves rounded up to a power of two
+    CoordPtrs<DIM> tgt;           // target planes by original index (seeding)
+};
+
+__device__ __forceinline__ unsigned long long spread21(unsigned int v) {   // 21 bits -> every third bit
+    unsigned long long x = v & 0x1FFFFFull;
+    x = (x | (x << 32)) & 0x1F00000000FFFFull;
+    x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+__device__ __forceinline__ unsigned int ordered_bits(float f) {          // monotone float -> uint map
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(unsigned int u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u);
+}
+
+// Per-level bounding boxes of the nodes, without contended atomics:
+//   k_bvh_wave_boxes : every wave (or aligned sub-wave segment of 32 / 16 positions, for the last levels) reduces the box
+//                      of its consecutive positions with a shuffle tree -> segbox[segment][2*DIM]
+//   k_bvh_node_boxes : one wave per node folds the node's wave boxes (segments of >= 64 positions are wave-aligned)
+template <int DIM>
+__global__ void k_bvh_wave_boxes(const CoordPtrs<DIM> cp, const int* __restrict__ perm, int n_valid, int seg_shift /* <= 6 */, unsigned int* __restrict__ segbox) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = i < n_valid;
+    const int j = act ? perm[i] : 0;
+    unsigned int v[2 * DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { const unsigned int a = act ? ordered_bits(cp.c[k][j]) : 0u; v[k] = act ? a : 0xFFFFFFFFu; v[DIM + k] = a; }
+    const int seg = 1 << seg_shift;                       // 64 (whole wave) or a sub-wave segment of 32 / 16 positions
+    for (int off = seg >> 1; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < DIM; k++) { v[k] = min(v[k], (unsigned int)__shfl_down((int)v[k], off, 64)); v[DIM + k] = max(v[DIM + k], (unsigned int)__shfl_down((int)v[DIM + k], off, 64)); }
+    }
+    if ((threadIdx.x & (seg - 1)) == 0 && (i < n_valid || seg == 64)) {
+        unsigned int* o = segbox + (size_t)(i >> seg_shift) * 2 * DIM;
+#pragma unroll
+        for (int k = 0; k < 2 * DIM; k++) o[k] = v[k];
+    }
+}
+template <int DIM>
+__global__ void k_bvh_node_boxes(const unsigned int* __restrict__ wavebox, int n_waves, int waves_per_node_shift, int n_nodes, unsigned int* __restrict__ boxes) {
+    const int node = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (node >= n_nodes) return;
+    const int w0 = node << waves_per_node_shift, w1 = min(w0 + (1 << waves_per_node_shift), n_waves);
+    unsigned int v[2 * DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { v[k] = 0xFFFFFFFFu; v[DIM + k] = 0u; }
+    for (int w = w0 + lane; w < w1; w += 64) {
+        const unsigned int* b = wavebox + (size_t)w * 2 * DIM;
+#pragma unroll
+        for (int k = 0; k < DIM; k++) { v[k] = min(v[k], b[k]); v[DIM + k] = max(v[DIM + k], b[DIM + k]); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < DIM; k++) { v[k] = min(v[k], (unsigned int)__shfl_down((int)v[k], off, 64)); v[DIM + k] = max(v[DIM + k], (unsigned int)__shfl_down((int)v[DIM + k], off, 64)); }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 2 * DIM; k++) boxes[(size_t)node * 2 * DIM + k] = v[k];
+    }
+}
+// sort key of every point at this level: (node id, coordinate along the node's widest axis)
+template <int DIM>
+__global__ void k_bvh_level_keys(const CoordPtrs<DIM> cp, const int* __restrict__ perm, int n_valid, int seg_shift, const unsigned int* __restrict__ boxes,
+                                 unsigned long long* __restrict__ keys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_valid) return;
+    const int node = i >> seg_shift;
+    const unsigned int* b = boxes + (size_t)node * 2 * DIM;
+    int axis = 0; float ext = -1.f;
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { const float e = from_ordered_bits(b[DIM + k]) - from_ordered_bits(b[k]); if (e > ext) { ext = e; axis = k; } }
+    const int j = perm[i];
+    float c = cp.c[0][j];
+#pragma unroll
+    for (int k = 1; k < DIM; k++) c = (axis == k) ? cp.c[k][j] : c;
+    keys[i] = ((unsigned long long)(unsigned int)node << 32) | ordered_bits(c);
+}
+
+template <int DIM>
+__global__ void k_bvh_gather(const CoordPtrs<DIM> cp, const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ nz, const uint32_t* __restrict__ rgba,
+                             const int* __restrict__ sorted_idx, int n_valid, int n_slots, BvhLeafT<DIM>* __restrict__ leaves, TgtRec* __restrict__ recs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    BvhLeafT<DIM>* lf = leaves + (i / BVH_LEAF); const int t = i % BVH_LEAF;
+    TgtRec r; r.x = INFINITY; r.y = INFINITY; r.z = INFINITY; r.idx = -1; r.nx = 0.f; r.ny = 0.f; r.nz = 0.f; r.rgba = 0u;
+    if (i < n_valid) {
+        const int j = sorted_idx[i];
+#pragma unroll
+        for (int k = 0; k < DIM; k++) lf->c[k][t] = cp.c[k][j];
+        lf->idx[t] = j;
+        r.x = cp.c[0][j]; r.y = cp.c[1][j]; r.z = cp.c[2][j]; r.idx = j;
+        if (nx) { r.nx = nx[j]; r.ny = ny[j]; r.nz = nz[j]; }
+        if (rgba) r.rgba = rgba[j];
+    } else {
+#pragma unroll
+        for (int k = 0; k < DIM; k++) lf->c[k][t] = (k < 3) ? INFINITY : 0.f;
+        lf->idx[t] = -1;
+    }
+    recs[i] = r;
+}
+
+// Boxes of the children of the internal nodes [first, first + count), bottom-up.  child_is_leaf: children are leaves.
+template <int DIM>
+__device__ __forceinline__ void child_box(const BvhLeafT<DIM>* __restrict__ leaves, const BvhNodeT<DIM>* __restrict__ nodes, int child, int Lp, int n_leaves,
+                                          bool child_is_leaf, float* lo, float* hi) {
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }          // empty box: lower bound = +inf
+    if (child_is_leaf) {
+        const int leaf = child - (Lp - 1);
+        if (leaf < n_leaves) {
+            const BvhLeafT<DIM>* lf = leaves + leaf;
+            for (int t = 0; t < BVH_LEAF; t++) {
+                if (lf->c[0][t] < INFINITY) {
+#pragma unroll
+                    for (int k = 0; k < DIM; k++) { lo[k] = fminf(lo[k], lf->c[k][t]); hi[k] = fmaxf(hi[k], lf->c[k][t]); }
+                }
+            }
+        }
+    } else {
+        const BvhNodeT<DIM>* nd = nodes + child;
+#pragma unroll
+        for (int k = 0; k < DIM; k++) { lo[k] = fminf(nd->lo[k][0], nd->lo[k][1]); hi[k] = fmaxf(nd->hi[k][0], nd->hi[k][1]); }
+    }
+}
+template <int DIM>
+__global__ void k_bvh_nodes(const BvhLeafT<DIM>* __restrict__ leaves, int n_leaves, int Lp, int first, int count, int children_are_leaves, BvhNodeT<DIM>* __restrict__ nodes) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const int node = first + t;
+    float lo0[DIM], hi0[DIM], lo1[DIM], hi1[DIM];
+    child_box<DIM>(leaves, nodes, 2 * node + 1, Lp, n_leaves, children_are_leaves != 0, lo0, hi0);
+    child_box<DIM>(leaves, nodes, 2 * node + 2, Lp, n_leaves, children_are_leaves != 0, lo1, hi1);
+    BvhNodeT<DIM>* out = nodes + node;
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { out->lo[k][0] = lo0[k]; out->lo[k][1] = lo1[k]; out->hi[k][0] = hi0[k]; out->hi[k][1] = hi1[k]; }
+}
+
+// 4-wide nodes from the finished binary records.  Virtual binary depth v = real depth + pad (pad = 1 when the real depth of
+// the leaves is odd: a virtual root whose second half is empty); 4-wide node (l, idx) is virtual node (2l, idx) and stores the
+// boxes of the virtual nodes (2l + 2, 4 idx + c), each of which is a child box of a real binary record one level up.
+template <int DIM>
+__global__ void k_bvh_quad_nodes(const BvhNodeT<DIM>* __restrict__ nodes, int pad, int Lq, BvhQuadT<DIM>* __restrict__ qnodes) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = (int)((((1ll << (2 * Lq)) - 1) / 3) * 4);
+    if (t >= total) return;
+    const int q = t >> 2, c = t & 3;
+    int l = 0; while ((int)(((1ll << (2 * (l + 1))) - 1) / 3) <= q) l++;         // level of 4-wide node q
+    const int idx = q - (int)(((1ll << (2 * l)) - 1) / 3);
+    const int rd = 2 * l + 2 - pad, ri = 4 * idx + c;                          // real depth / index of child c
+    float lo[DIM], hi[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { lo[k] = INFINITY; hi[k] = -INFINITY; }      // empty box: lower bound = +inf
+    if (ri < (1 << rd)) {
+        const BvhNodeT<DIM>* nd = nodes + ((1 << (rd - 1)) - 1 + (ri >> 1));
+#pragma unroll
+        for (int k = 0; k < DIM; k++) { lo[k] = nd->lo[k][ri & 1]; hi[k] = nd->hi[k][ri & 1]; }
+    }
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { qnodes[q].lo[k][c] = lo[k]; qnodes[q].hi[k][c] = hi[k]; }
+}
+
+// Lower bounds of the fp32 squared distance from the query to any point of the two child boxes, both at once (packed
+// f32), accumulated in the SAME order as the point distance: ((e0^2 + e1^2) + e2^2) [+ e3^2 + e4^2 + e5^2].
+template <int DIM>
+__device__ __forceinline__ f2 pair_lb(const BvhNodeT<DIM>* __restrict__ nd, const f2* p2) {
+    f2 acc;
+#pragma unroll
+    for (int k = 0; k < DIM; k++) {
+        const f2 lo = *(const f2*)nd->lo[k], hi = *(const f2*)nd->hi[k];
+        const f2 a = lo - p2[k], b = p2[k] - hi;
+        const f2 e = {fmaxf(fmaxf(a.x, b.x), 0.f), fmaxf(fmaxf(a.y, b.y), 0.f)};
+        const f2 sq = e * e;
+        acc = (k == 0) ? sq : acc + sq;
+    }
+    return acc;
+}
+
+// Evaluate the 8 points of a leaf against the lane's query; exact lexicographic (d2, lowest index) update.
+// best2 follows the smallest distance among all evaluated points OTHER than the current winner (see k_knn_bvh).
+template <int DIM>
+__device__ __forceinline__ void leaf_eval(const BvhLeafT<DIM>* __restrict__ lf, int leaf, const f2* p2, float& best, int& bi, int& bpos, float& best2) {
+    float dd[BVH_LEAF];
+    float m = FLT_MAX;
+#pragma unroll
+    for (int t = 0; t < BVH_LEAF; t += 2) {
+        f2 d;
+#pragma unroll
+        for (int k = 0; k < DIM; k++) {
+            const f2 q = *(const f2*)(&lf->c[k][t]);
+            const f2 e = p2[k] - q;
+            const f2 sq = e * e;
+            d = (k == 0) ? sq : d + sq;
+        }
+        dd[t] = d.x; dd[t + 1] = d.y;
+        m = fminf(fminf(m, d.x), d.y);
+    }
+    if (m <= best) {                     // something in this leaf ties or beats the running best (or IS the running best)
+#pragma unroll
+        for (int t = 0; t < BVH_LEAF; t++) {
+            const int j = lf->idx[t];
+            const bool take = (dd[t] < best) | ((dd[t] == best) & (j < bi));     // first minimum = lowest original index
+            const float other = take ? best : ((j != bi) ? dd[t] : FLT_MAX);      // the dethroned winner, or a non-winning point
+            best2 = fminf(best2, other);
+            best = take ? dd[t] : best; bi = take ? j : bi; bpos = take ? leaf * BVH_LEAF + t : bpos;
+        }
+    } else best2 = fminf(best2, m);      // nobody here can win: all 8 are "others"
+}
+
+// Temporal seeding: ICP moves the queries a little per iteration, so the previous iteration's neighbour j0 is a
+// good first candidate.  The traversal starts with (best, bi) = (d2(p, target[j0]), j0) -- a real candidate evaluated
+// with the same fp32 formula -- and the final (d2, index) is still the exact lexicographic minimum over ALL targets
+// (a box is skipped only if its lower bound exceeds the running best).
+template <int DIM>
+__device__ __forceinline__ void seed_from_previous(const int* __restrict__ nn_pos, int use_prev, const BvhViewT<DIM>& bv, int k, const float* p, float& best, int& bi, int& bpos) {
+    if (!use_prev) return;
+    const int q0 = nn_pos[k];                             // POSITION (8 * leaf + slot) of the previous neighbour
+    if (q0 < 0) return;
+    float t[DIM]; int j0;
+    if (DIM == 3) { const float4 r = *(const float4*)(bv.recs + q0); t[0] = r.x; t[1] = r.y; t[2] = r.z; j0 = __float_as_int(r.w); }
+    else {
+        const BvhLeafT<DIM>* lf = bv.leaves + (q0 >> 3);
+#pragma unroll
+        for (int q = 0; q < DIM; q++) t[q] = lf->c[q][q0 & 7];
+        j0 = lf->idx[q0 & 7];
+    }
+    float d = 0.f;
+#pragma unroll
+    for (int q = 0; q < DIM; q++) { const float e = p[q] - t[q]; d = (q == 0) ? e * e : d + e * e; }
+    if (d < best) { best = d; bi = j0; bpos = q0; }
+}
+
+// Per-lane traversal state of the complete binary tree in heap order: three registers -- depth, index within the level
+// and a bit mask of the levels whose far sibling is still pending.  The only per-level storage is the far sibling's
+// lower bound, kept as a 16-bit truncated (never larger, hence conservative) value in LDS: 2 B x depth per lane, which
+// leaves room for the full 32 waves per CU.
+struct TravState { int depth; int idx; unsigned int pending; bool alive; };
+
+__device__ __forceinline__ void trav_pop(TravState& st, const unsigned short* __restrict__ lb16, int tid, int nthreads, float best, float& minlb) {
+    while (!st.alive && st.pending) {                     // deepest pending sibling that survives the (possibly improved) bound
+        const int d = 31 - __clz((int)st.pending);
+        st.pending &= ~(1u << d);
+        const float lb = __uint_as_float((unsigned int)lb16[d * nthreads + tid] << 16);      // <= true bound
+        if (!(lb * 0.99999f > best)) { st.idx = (st.idx >> (st.depth - d - 1)) ^ 1; st.depth = d + 1; st.alive = true; }
+        else minlb = fminf(minlb, lb);                    // skipped subtree: everything in it is at least this far
+    }
+}
+
+// ---- 4-wide walk -------------------------------------------------------------------------------------------------------
+// Same exactness argument as the binary walk (a box is skipped only if its lower bound, computed with the operation order
+// of the point distance, exceeds the running best), half the depth.  Per-lane state: level, index within the level and
+// 4 pending-child bits per level in one 64-bit mask; the pending children's bounds live in LDS as 4 x 16-bit truncated
+// floats per level and lane (one 8-byte access).  Siblings are visited in ascending order of their bound.
+struct QuadState { int L; int idx; unsigned long long pending; bool alive; };
+
+template <int DIM>
+__device__ __forceinline__ void quad_lb(const BvhQuadT<DIM>* __restrict__ nd, const f2* p2, f2& l01, f2& l23) {
+#pragma unroll
+    for (int k = 0; k < DIM; k++) {
+        const f2 lo0 = *(const f2*)&nd->lo[k][0], lo1 = *(const f2*)&nd->lo[k][2], hi0 = *(const f2*)&nd->hi[k][0], hi1 = *(const f2*)&nd->hi[k][2];
+        const f2 a0 = lo0 - p2[k], b0 = p2[k] - hi0, a1 = lo1 - p2[k], b1 = p2[k] - hi1;
+        const f2 e0 = {fmaxf(fmaxf(a0.x, b0.x), 0.f), fmaxf(fmaxf(a0.y, b0.y), 0.f)};
+        const f2 e1 = {fmaxf(fmaxf(a1.x, b1.x), 0.f), fmaxf(fmaxf(a1.y, b1.y), 0.f)};
+        const f2 s0 = e0 * e0, s1 = e1 * e1;
+        l01 = (k == 0) ? s0 : l01 + s0;
+        l23 = (k == 0) ? s1 : l23 + s1;
+    }
+}
+
+__device__ __forceinline__ void quad_pop(QuadState& st, const uint2* __restrict__ lbq, int tid, int nthreads, float best, float& minlb) {
+    while (!st.alive && st.pending) {
+        const int lv = (63 - __clzll((long long)st.pending)) >> 2;                // deepest level with pending children
+        const unsigned int bits = (unsigned int)(st.pending >> (4 * lv)) & 0xFu;
+        const uint2 w = lbq[lv * nthreads + tid];
+        const float l0 = (bits & 1u) ? __uint_as_float(w.x << 16) : FLT_MAX, l1 = (bits & 2u) ? __uint_as_float(w.x & 0xFFFF0000u) : FLT_MAX;
+        const float l2 = (bits & 4u) ? __uint_as_float(w.y << 16) : FLT_MAX, l3 = (bits & 8u) ? __uint_as_float(w.y & 0xFFFF0000u) : FLT_MAX;
+        const float m = fminf(fminf(l0, l1), fminf(l2, l3));                      // truncated bounds: <= the true ones
+        if (m * 0.99999f > best) {                                               // the nearest pending sibling is out: so are the others
+            minlb = fminf(minlb, m);
+            st.pending &= ~(0xFull << (4 * lv));
+        } else {
+            const int c = (l0 == m) ? 0 : (l1 == m) ? 1 : (l2 == m) ? 2 : 3;
+            st.pending &= ~(1ull << (4 * lv + c));
+            st.idx = ((st.idx >> (2 * (st.L - lv))) << 2) | c; st.L = lv + 1; st.alive = true;
+        }
+    }
+}
+
+// The walk is a chain of dependent loads, each a trip to L2 or HBM.  A seeded query already knows where it will most
+// likely end up: in or next to the leaf of its previous neighbour, whose ancestors are known arithmetically in the implicit
+// layout.  Touching that whole root-to-leaf path up front turns the chain of misses into ONE round of parallel misses followed
+// by cache hits.  (The lowest 8 levels; anything above is shared by everybody and hot.)
+template <int DIM>
+__device__ __forceinline__ unsigned int quad_prefetch_path(const BvhViewT<DIM>& bv, int leaf) {
+    // plain loads whose values are only consumed (by an empty asm) AFTER the walk: nothing waits for them specially, they
+    // simply travel together with the walk's first node load
+    unsigned int sink = *(const unsigned int*)(bv.leaves + leaf);
+    if (DIM == 6) sink |= *((const unsigned int*)(bv.leaves + leaf) + 32);
+    unsigned int t[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {                         // branch-free (levels above the root clamp to the root): the loads issue back to back
+        const int L = max(bv.Lq - 1 - u, 0), sh = min(2 * (u + 1), 2 * bv.Lq);
+        const unsigned int* nd = (const unsigned int*)(bv.qnodes + ((0x5555555555555555ull & ((1ull << (2 * L)) - 1ull)) + (unsigned long long)(leaf >> sh)));
+        t[u] = nd[31];
+        if (DIM == 6) t[u] |= nd[63];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) sink |= t[u];
+    return sink;
+}
+
+template <int DIM>
+__device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const f2* p2, QuadState& st,
+                                         float& best, int& bi, int& bpos, float& best2, float& minlb, uint2* __restrict__ lbq, int tid, int nthreads) {
+    const int Lq = bv.Lq;
+    while (st.alive) {
+        while (st.alive && st.L < Lq) {
+            f2 l01, l23;
+            quad_lb<DIM>(bv.qnodes + ((0x5555555555555555ull & ((1ull << (2 * st.L)) - 1ull)) + (unsigned long long)st.idx), p2, l01, l23);
+            const float m = fminf(fminf(l01.x, l01.y), fminf(l23.x, l23.y));
+            const bool s0 = !(l01.x * 0.99999f > best), s1 = !(l01.y * 0.99999f > best), s2 = !(l23.x * 0.99999f > best), s3 = !(l23.y * 0.99999f > best);
+            minlb = fminf(minlb, fminf(fminf(s0 ? FLT_MAX : l01.x, s1 ? FLT_MAX : l01.y), fminf(s2 ? FLT_MAX : l23.x, s3 ? FLT_MAX : l23.y)));   // skipped right here
+            if (!(m * 0.99999f > best)) {
+                const int c = (l01.x == m) ? 0 : (l01.y == m) ? 1 : (l23.x == m) ? 2 : 3;
+                const unsigned int pend = ((s0 ? 1u : 0u) | (s1 ? 2u : 0u) | (s2 ? 4u : 0u) | (s3 ? 8u : 0u)) & ~(1u << c);
+                if (pend) {
+                    uint2 w;
+                    w.x = (__float_as_uint(l01.x) >> 16) | (__float_as_uint(l01.y) & 0xFFFF0000u);
+                    w.y = (__float_as_uint(l23.x) >> 16) | (__float_as_uint(l23.y) & 0xFFFF0000u);
+                    lbq[st.L * nthreads + tid] = w;
+                    st.pending |= (unsigned long long)pend << (4 * st.L);
+                }
+                st.idx = (st.idx << 2) | c; st.L++;
+            } else st.alive = false;                      // all four children pruned
+            quad_pop(st, lbq, tid, nthreads, best, minlb);
+        }
+        if (st.alive) {
+            leaf_eval<DIM>(bv.leaves + st.idx, st.idx, p2, best, bi, bpos, best2);
+            st.alive = false;
+            quad_pop(st, lbq, tid, nthreads, best, minlb);
+        }
+    }
+}
+
+// XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (block b runs on the XCD group b % 8), each
+// with a private 4 MiB L2.  With Morton-sorted queries, giving every XCD group ONE contiguous slice of the sorted list
+// means its L2 only has to hold the part of the tree under that slice (plus the shared top levels) instead of all of it.
+__device__ __forceinline__ int xcd_contiguous_block(int b, int nb) {
+    const int q = nb >> 3, r = nb & 7, x = b & 7, j = b >> 3;        // XCD group x owns q (+1 if x < r) consecutive logical blocks
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// Every lane walks the tree on its own for its own query.  Measured on MI355X (370k x 370k, DIM 3): ~26 node records and
+// ~3 leaves per query, ~50 % of the wave time waiting on dependent loads, ~33 % of the lanes active on average (traversal
+// lengths differ per lane).  What moved it: Morton-sorted queries + XCD-contiguous slices (L2 hit 59 % -> 89 %), the
+// 2-byte-per-level stack (occupancy), temporal seeding, and -- once ICP has converged -- the verify-and-skip test below,
+// which retires whole waves without a traversal.  Tried and rejected (slower, see git history): wave-packet
+// traversal with scalar node loads (the union of 64 lanes' subtrees is 3x larger), persistent lanes with wave-level
+// refill (fewer waves in flight), a second cooperative pass for queries over a step budget.
+template <int DIM>
+__device__ __forceinline__ void knn_load_query(const KnnParams& kp, int k, float* p) {
+    const int i = kp.sel ? kp.sel[k] : k;
+    p[0] = kp.sx[i]; p[1] = kp.sy[i]; p[2] = kp.sz[i];
+    if (!kp.pretransformed) { float a, b, c; xform_point(kp.ps->pose, p[0], p[1], p[2], a, b, c); p[0] = a; p[1] = b; p[2] = c; }
+    if (DIM == 6) { p[3 % DIM] = kp.scr[i]; p[4 % DIM] = kp.scg[i]; p[5 % DIM] = kp.scb[i]; }
+}
+
+// Incremental search.  The last full search left, for this query, a lower bound L on the distance to every target
+// other than its neighbour j0.  The query has since moved by delta, so every other target is still at least
+// L - delta away (triangle inequality); if the re-evaluated distance to j0 is strictly below that, j0 is still THE
+// unique fp32 argmin and the traversal is skipped.  All margins (1e-6 relative) dominate the fp32 rounding of the
+// distance formula (< 4e-7), so the result is bit-identical to a full search; otherwise a full search runs.
+// Seeds (best, bi) with the previous neighbour either way.
+template <int DIM>
+__device__ __forceinline__ bool knn_try_verify(const KnnParams& kp, const BvhViewT<DIM>& bv, int k, const float* p, float& best, int& bi, int& bpos, float& lb_others) {
+    seed_from_previous<DIM>(kp.nn_raw, kp.use_prev, bv, k, p, best, bi, bpos);
+    if (kp.incremental && kp.use_prev && bi >= 0) {
+        const float4 s = kp.qstate[k];
+        const float ex = p[0] - s.x, ey = p[1] - s.y, ez = p[2] - s.z;
+        const float delta = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.000001f + 1e-30f;
+        const float lbn = (s.w - delta) * 0.999999f;
+        if (sqrtf(best) * 1.000001f < lbn) { lb_others = lbn; return true; }
+    }
+    return false;
+}
+
+template <int DIM>
+__device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, const float* p, float best, int bpos, float lb_others) {
+    if (kp.qstate) { float4 s; s.x = p[0]; s.y = p[1]; s.z = p[2]; s.w = lb_others; kp.qstate[k] = s; }
+    if (kp.nn_raw) kp.nn_raw[k] = bpos;
+    if (kp.d2_out) kp.d2_out[k] = best;
+}
+
+template <int DIM>
+__device__ __forceinline__ void knn_bvh_query(const KnnParams& kp, const BvhViewT<DIM>& bv, int k, uint2* __restrict__ lbq, int tid,
+                                              float& best, int& bi, int& bpos) {
+    float p[DIM];
+    knn_load_query<DIM>(kp, k, p);
+    best = FLT_MAX; bi = -1; bpos = -1;
+    float lb_others = 0.f;               // lower bound on the (real) distance from p to every target except bi
+    if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
+        if (!knn_try_verify<DIM>(kp, bv, k, p, best, bi, bpos, lb_others)) {
+            f2 p2[DIM];
+#pragma unroll
+            for (int q = 0; q < DIM; q++) { p2[q].x = p[q]; p2[q].y = p[q]; }
+            float best2 = FLT_MAX, minlb = FLT_MAX;
+            unsigned int touched = 0u;
+            if (ICP_PREFETCH_PATH && bpos >= 0) touched = quad_prefetch_path<DIM>(bv, bpos >> 3);
+            QuadState st; st.L = 0; st.idx = 0; st.pending = 0ull; st.alive = true;
+            quad_run<DIM>(bv, p2, st, best, bi, bpos, best2, minlb, lbq, tid, BVH_THREADS);
+            asm volatile("" ::"v"(touched));
+            lb_others = sqrtf(fminf(best2, minlb)) * 0.999999f;
+        }
+    }
+    knn_store_state<DIM>(kp, k, p, best, bpos, lb_others);
+}
+
+// Which query does this lane serve?  Either position t of the (Morton-sorted) query order, or -- second pass of the
+// incremental search -- entry t of the work list, whose length is only known on the device: the launch covers the worst case
+// and blocks past the end retire at once; the XCD-contiguous slices are cut over the blocks actually in use.
+__device__ __forceinline__ int knn_bvh_lane_query(const KnnParams& kp, const int* __restrict__ qorder, int tid) {
+    if (kp.work_items) {
+        const int n = *kp.work_n, nb = (n + BVH_THREADS - 1) / BVH_THREADS;
+        if ((int)blockIdx.x >= nb) return -1;
+        const int t = xcd_contiguous_block(blockIdx.x, nb) * BVH_THREADS + tid;
+        return t < n ? kp.work_items[t] : -1;
+    }
+    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS + tid;
+    if (t >= kp.n) return -1;
+    return qorder ? qorder[t] : t;                        // spatially sorted queries: neighbouring lanes walk similar paths
+}
+
+template <int DIM>
+__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder) {
+    extern __shared__ uint2 bvh_lbq[];                    // [Lq][BVH_THREADS] pending-sibling bounds
+    const int tid = threadIdx.x;
+    const int k = knn_bvh_lane_query(kp, qorder, tid);
+    if (k < 0) return;
+    float best; int bi, bpos;
+    knn_bvh_query<DIM>(kp, bv, k, bvh_lbq, tid, best, bi, bpos);
+    icp_match_t m;
+    if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
+    kp.out[k] = m;
+}
+
+// First pass of the incremental search: a streaming kernel that re-evaluates every query against its previous neighbour.
+// Verified queries are finished here; the others are appended to the work list for the tree walk (one wave-aggregated
+// atomic per wave; the list order varies from run to run, the per-query results do not depend on it).  Packing the
+// survivors densely matters: left in place they would keep almost every wave walking the tree at a few lanes' utilisation.
+constexpr int VERIFY_THREADS = 256;
+template <int DIM>
+__global__ __launch_bounds__(VERIFY_THREADS) void k_knn_verify(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder) {
+    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * VERIFY_THREADS + threadIdx.x;
+    bool push = false; int k = -1;
+    if (t < kp.n) {
+        k = qorder ? qorder[t] : t;
+        float p[DIM];
+        knn_load_query<DIM>(kp, k, p);
+        float best = FLT_MAX, lb_others = 0.f; int bi = -1, bpos = -1;
+        if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
+            push = !knn_try_verify<DIM>(kp, bv, k, p, best, bi, bpos, lb_others);
+        }
+        if (!push) {
+            knn_store_state<DIM>(kp, k, p, best, bpos, lb_others);
+            icp_match_t m;
+            if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
+            kp.out[k] = m;
+        }
+    }
+    const unsigned long long mask = __ballot(push);
+    if (mask) {
+        const int lane = threadIdx.x & 63;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(kp.work_n, __popcll(mask));
+        base = __shfl(base, 0, WAVE);
+        if (push) kp.work_items[base + __popcll(mask & ((1ull << lane) - 1ull))] = k;
+    }
+}

@@ -1,0 +1,354 @@
+// dev_solve.hpp -- fp64 small dense solvers and k_reduce_solve.
+// Part of icp_device.hpp (included from there, inside namespace icpdev); see that file for the build contract.
+// ------------------------------------------------------------------------------------------------
+// fp64 small dense solvers, run by one thread of k_reduce_solve.
+template <int n>
+__device__ inline void jacobi_eig_sym(double* A /* n x n, destroyed */, double* V, double* ev) {
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+#pragma unroll
+        for (int j = 0; j < n; j++) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 50; sweep++) {
+        double off = 0.0, dg = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+#pragma unroll
+            for (int j = 0; j < n; j++) { if (i != j) off += A[i * n + j] * A[i * n + j]; else dg += A[i * n + j] * A[i * n + j]; }
+        }
+        if (off <= 1e-300 || off <= 1e-34 * dg) break;
+#pragma unroll
+        for (int p = 0; p < n - 1; p++) {
+#pragma unroll
+            for (int q = p + 1; q < n; q++) {
+                const double apq = A[p * n + q];
+                if (apq != 0.0) {
+                    const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                    for (int k = 0; k < n; k++) { const double akp = A[k * n + p], akq = A[k * n + q]; A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq; }
+#pragma unroll
+                    for (int k = 0; k < n; k++) { const double apk = A[p * n + k], aqk = A[q * n + k]; A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk; }
+#pragma unroll
+                    for (int k = 0; k < n; k++) { const double vkp = V[k * n + p], vkq = V[k * n + q]; V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq; }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < n; i++) ev[i] = A[i * n + i];
+}
+
+// Fast path: when the 6x6 normal matrix is comfortably full rank (every LDL^T pivot > 1e-9 x its diagonal entry,
+// i.e. far above the (6 eps_f32)^2 = 5e-13 relative eigenvalue cut of the SVD rule) the truncated-SVD solution IS the
+// plain solution and an unrolled fp64 LDL^T gives it in ~100 flops.  Otherwise: Jacobi eigen-decomposition.
+__device__ __forceinline__ bool solve_ldlt6(const double* sums, double* x) {
+    double a00 = sums[0], a01 = sums[1], a02 = sums[2], a03 = sums[3], a04 = sums[4], a05 = sums[5];
+    double a11 = sums[6], a12 = sums[7], a13 = sums[8], a14 = sums[9], a15 = sums[10];
+    double a22 = sums[11], a23 = sums[12], a24 = sums[13], a25 = sums[14];
+    double a33 = sums[15], a34 = sums[16], a35 = sums[17];
+    double a44 = sums[18], a45 = sums[19];
+    double a55 = sums[20];
+    const double g0 = sums[21], g1 = sums[22], g2 = sums[23], g3 = sums[24], g4 = sums[25], g5 = sums[26];
+    const double tol = 1e-9;
+    const double o00 = a00, o11 = a11, o22 = a22, o33 = a33, o44 = a44, o55 = a55;
+    // column 0
+    const double d0 = a00; if (!(d0 > tol * o00) || !(o00 > 0)) return false;
+    const double l10 = a01 / d0, l20 = a02 / d0, l30 = a03 / d0, l40 = a04 / d0, l50 = a05 / d0;
+    a11 -= l10 * a01; a12 -= l10 * a02; a13 -= l10 * a03; a14 -= l10 * a04; a15 -= l10 * a05;
+    a22 -= l20 * a02; a23 -= l20 * a03; a24 -= l20 * a04; a25 -= l20 * a05;
+    a33 -= l30 * a03; a34 -= l30 * a04; a35 -= l30 * a05;
+    a44 -= l40 * a04; a45 -= l40 * a05;
+    a55 -= l50 * a05;
+    const double d1 = a11; if (!(d1 > tol * o11)) return false;
+    const double l21 = a12 / d1, l31 = a13 / d1, l41 = a14 / d1, l51 = a15 / d1;
+    a22 -= l21 * a12; a23 -= l21 * a13; a24 -= l21 * a14; a25 -= l21 * a15;
+    a33 -= l31 * a13; a34 -= l31 * a14; a35 -= l31 * a15;
+    a44 -= l41 * a14; a45 -= l41 * a15;
+    a55 -= l51 * a15;
+    const double d2 = a22; if (!(d2 > tol * o22)) return false;
+    const double l32 = a23 / d2, l42 = a24 / d2, l52 = a25 / d2;
+    a33 -= l32 * a23; a34 -= l32 * a24; a35 -= l32 * a25;
+    a44 -= l42 * a24; a45 -= l42 * a25;
+    a55 -= l52 * a25;
+    const double d3 = a33; if (!(d3 > tol * o33)) return false;
+    const double l43 = a34 / d3, l53 = a35 / d3;
+    a44 -= l43 * a34; a45 -= l43 * a35;
+    a55 -= l53 * a35;
+    const double d4 = a44; if (!(d4 > tol * o44)) return false;
+    const double l54 = a45 / d4;
+    a55 -= l54 * a45;
+    const double d5 = a55; if (!(d5 > tol * o55)) return false;
+    // L z = g
+    const double z0 = g0;
+    const double z1 = g1 - l10 * z0;
+    const double z2 = g2 - l20 * z0 - l21 * z1;
+    const double z3 = g3 - l30 * z0 - l31 * z1 - l32 * z2;
+    const double z4 = g4 - l40 * z0 - l41 * z1 - l42 * z2 - l43 * z3;
+    const double z5 = g5 - l50 * z0 - l51 * z1 - l52 * z2 - l53 * z3 - l54 * z4;
+    // D y = z ; L^T x = y
+    const double x5 = z5 / d5;
+    const double x4 = z4 / d4 - l54 * x5;
+    const double x3 = z3 / d3 - l43 * x4 - l53 * x5;
+    const double x2 = z2 / d2 - l32 * x3 - l42 * x4 - l52 * x5;
+    const double x1 = z1 / d1 - l21 * x2 - l31 * x3 - l41 * x4 - l51 * x5;
+    const double x0 = z0 / d0 - l10 * x1 - l20 * x2 - l30 * x3 - l40 * x4 - l50 * x5;
+    x[0] = x0; x[1] = x1; x[2] = x2; x[3] = x3; x[4] = x4; x[5] = x5;
+    return true;
+}
+
+__device__ inline void solve_normal_svd(const double* sums /* 21 + 6 */, double* x) {
+    if (solve_ldlt6(sums, x)) return;
+    double A[36], V[36], ev[6];
+    int q = 0;
+    for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { A[a * 6 + c] = sums[q]; A[c * 6 + a] = sums[q]; q++; }
+    const double* g = sums + 21;
+    jacobi_eig_sym<6>(A, V, ev);
+    double emax = 0.0;
+    for (int i = 0; i < 6; i++) emax = fmax(emax, ev[i]);
+    const double thr = 6.0 * 1.1920928955078125e-07;
+    for (int i = 0; i < 6; i++) x[i] = 0.0;
+    for (int j = 0; j < 6; j++) {
+        if (!(ev[j] > thr * thr * emax)) continue;
+        double vg = 0.0;
+        for (int i = 0; i < 6; i++) vg += V[i * 6 + j] * g[i];
+        const double coef = vg / ev[j];
+        for (int i = 0; i < 6; i++) x[i] += V[i * 6 + j] * coef;
+    }
+}
+
+// FullPivLU::solve with its rank rule in fp64 (ICPOptimizer.h:866-868).
+__device__ inline void solve_fullpiv_lu6(double* M, double* rhs, double* x) {
+    const int n = 6;
+    int colp[6];
+    for (int i = 0; i < n; i++) colp[i] = i;
+    double maxpiv = 0.0; int rank = n;
+    for (int k = 0; k < n; k++) {
+        int pr = k, pc = k; double best = -1.0;
+        for (int i = k; i < n; i++) for (int j = k; j < n; j++) { const double v = fabs(M[i * n + j]); if (v > best) { best = v; pr = i; pc = j; } }
+        if (best > maxpiv) maxpiv = best;
+        if (best == 0.0) { rank = k; break; }
+        if (pr != k) { for (int j = 0; j < n; j++) { const double t = M[k * n + j]; M[k * n + j] = M[pr * n + j]; M[pr * n + j] = t; } const double t = rhs[k]; rhs[k] = rhs[pr]; rhs[pr] = t; }
+        if (pc != k) { for (int i = 0; i < n; i++) { const double t = M[i * n + k]; M[i * n + k] = M[i * n + pc]; M[i * n + pc] = t; } const int t = colp[k]; colp[k] = colp[pc]; colp[pc] = t; }
+        for (int i = k + 1; i < n; i++) {
+            const double f = M[i * n + k] / M[k * n + k];
+            for (int j = k + 1; j < n; j++) M[i * n + j] -= f * M[k * n + j];
+            rhs[i] -= f * rhs[k];
+        }
+    }
+    const double thr = 1.1920928955078125e-07 * 6.0;
+    int r = 0;
+    for (int k = 0; k < rank; k++) { if (fabs(M[k * n + k]) > maxpiv * thr) r++; else break; }
+    double y[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = r - 1; k >= 0; k--) { double s = rhs[k]; for (int j = k + 1; j < r; j++) s -= M[k * n + j] * y[j]; y[k] = s / M[k * n + k]; }
+    for (int k = 0; k < n; k++) x[colp[k]] = (k < r) ? y[k] : 0.0;
+}
+
+// Rotation of the weighted Procrustes problem: R = U diag(1,1,det(UV^T)) V^T of A = U S V^T
+// (ProcrustesAligner.h:55-64).  V from the fp64 eigen-decomposition of A^T A (descending), U_c = A v_c/|A v_c|
+// for the two leading columns.  With c = U_0 x U_1 the reference's product collapses to
+//   R = U_0 V_0^T + U_1 V_1^T + det(V) * c * V_2^T
+// (flipping the sign of the third left vector flips det(UV^T) too), which stays well defined when sigma_3 -> 0.
+__device__ inline void procrustes_rotation(const double* A /* 3x3 row-major */, double* R) {
+    double B[9], V[9], ev[3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += A[k * 3 + i] * A[k * 3 + j]; B[i * 3 + j] = s; }
+    jacobi_eig_sym<3>(B, V, ev);
+    int o[3] = {0, 1, 2};
+    for (int a = 0; a < 2; a++) for (int b = a + 1; b < 3; b++) if (ev[o[b]] > ev[o[a]]) { const int t = o[a]; o[a] = o[b]; o[b] = t; }
+    double Vs[9], U[9];
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) Vs[r * 3 + c] = V[r * 3 + o[c]];
+    const double s0 = sqrt(fmax(ev[o[0]], 0.0));
+    for (int c = 0; c < 2; c++) {
+        double u[3];
+        for (int r = 0; r < 3; r++) { u[r] = 0; for (int k = 0; k < 3; k++) u[r] += A[r * 3 + k] * Vs[k * 3 + c]; }
+        if (c == 1) {   // re-orthogonalise against column 0 (exact in exact arithmetic)
+            const double dp = u[0] * U[0] + u[1] * U[3] + u[2] * U[6];
+            u[0] -= dp * U[0]; u[1] -= dp * U[3]; u[2] -= dp * U[6];
+        }
+        double nr = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        if (!(nr > 1e-13 * s0) || !(nr > 0.0)) {   // rank-deficient A: any unit vector orthogonal to what we have
+            if (c == 0) { u[0] = 1; u[1] = 0; u[2] = 0; }
+            else {
+                const double a0 = U[0], a1 = U[3], a2 = U[6];
+                const int kmin = fabs(a0) < fabs(a1) ? (fabs(a0) < fabs(a2) ? 0 : 2) : (fabs(a1) < fabs(a2) ? 1 : 2);
+                const double dp = (kmin == 0 ? a0 : (kmin == 1 ? a1 : a2));
+                u[0] = (kmin == 0 ? 1.0 : 0.0) - dp * a0; u[1] = (kmin == 1 ? 1.0 : 0.0) - dp * a1; u[2] = (kmin == 2 ? 1.0 : 0.0) - dp * a2;
+            }
+            nr = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        }
+        for (int r = 0; r < 3; r++) U[r * 3 + c] = u[r] / nr;
+    }
+    U[2] = U[3] * U[7] - U[6] * U[4]; U[5] = U[6] * U[1] - U[0] * U[7]; U[8] = U[0] * U[4] - U[3] * U[1];
+    const double detV = Vs[0] * (Vs[4] * Vs[8] - Vs[5] * Vs[7]) - Vs[1] * (Vs[3] * Vs[8] - Vs[5] * Vs[6]) + Vs[2] * (Vs[3] * Vs[7] - Vs[4] * Vs[6]);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+        R[r * 3 + c] = (U[r * 3] * Vs[c * 3] + U[r * 3 + 1] * Vs[c * 3 + 1]) + detV * U[r * 3 + 2] * Vs[c * 3 + 2];
+}
+
+// fp32 helpers with the Eigen fixed-size evaluation orders used by the reference's pose algebra
+__device__ inline void mat4_mul_f32(const float* A, const float* B, float* C) {   // column-major, sequential over k
+    float T[16];
+    for (int c = 0; c < 4; c++) for (int r = 0; r < 4; r++) {
+        float acc = A[0 * 4 + r] * B[c * 4 + 0];
+        acc = acc + A[1 * 4 + r] * B[c * 4 + 1];
+        acc = acc + A[2 * 4 + r] * B[c * 4 + 2];
+        acc = acc + A[3 * 4 + r] * B[c * 4 + 3];
+        T[c * 4 + r] = acc;
+    }
+    for (int i = 0; i < 16; i++) C[i] = T[i];
+}
+__device__ inline void mat3_mul_f32(const float* A, const float* B, float* C) {   // row-major, e0 + (e1 + e2)
+    float T[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) T[r * 3 + c] = A[r * 3] * B[c] + (A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c]);
+    for (int i = 0; i < 9; i++) C[i] = T[i];
+}
+__device__ inline void set_pose_f32(float* pose, const float* R, const float* t) {
+    for (int i = 0; i < 16; i++) pose[i] = (i % 5 == 0) ? 1.f : 0.f;
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) pose[c * 4 + r] = R[r * 3 + c]; pose[12 + r] = t[r]; }
+}
+// (R^-1)^T by fp64 cofactors rounded once (same operation order as the oracle's normal_matrix)
+__device__ __host__ inline void normal_matrix_from_pose(const float* pose, float* N) {
+    const double a = pose[0], b = pose[4], c = pose[8];
+    const double d = pose[1], e = pose[5], f = pose[9];
+    const double g = pose[2], h = pose[6], i = pose[10];
+    const double c00 = e * i - f * h, c01 = f * g - d * i, c02 = d * h - e * g;
+    const double c10 = c * h - b * i, c11 = a * i - c * g, c12 = b * g - a * h;
+    const double c20 = b * f - c * e, c21 = c * d - a * f, c22 = a * e - b * d;
+    const double det = (a * c00 + b * c01) + c * c02;
+    N[0] = (float)(c00 / det); N[1] = (float)(c01 / det); N[2] = (float)(c02 / det);
+    N[3] = (float)(c10 / det); N[4] = (float)(c11 / det); N[5] = (float)(c12 / det);
+    N[6] = (float)(c20 / det); N[7] = (float)(c21 / det); N[8] = (float)(c22 / det);
+}
+
+struct SolveParams {
+    const double* partials; int nblocks;   // [NSUM][nblocks]
+    double* totals; unsigned* ticket;      // NSUM reduced sums; arrival counter (0 between launches)
+    PoseState* ps;
+    int metric; int phase;         // phase 0: full solve (p2p / p2plane) or means only (symmetric); phase 1: symmetric solve
+    icp_iter_stats* stats;         // record slot of this iteration (may be null)
+    int n_src;
+    double* sums_out;              // optional copy of the reduced sums (NSUM doubles)
+    int update_pose;               // 0: only reduce (icp_correspond)
+    const double* rmse_partials; int rmse_blocks;   // unused here
+};
+
+// Grid of NSUM blocks: block a folds the partials of sum a in a fixed order (lanes stride the producer blocks, shuffle tree,
+// then the waves in order) -- identical on every run and independent of block scheduling.  The block that finishes last (ticket
+// counter, release/acquire fences at agent scope) gathers the NSUM totals and runs the small fp64 solve + pose composition.
+constexpr int SOLVE_THREADS = 256;
+__global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParams sp) {
+    __shared__ double tot[NSUM];
+    __shared__ double wsum[SOLVE_THREADS / WAVE];
+    __shared__ int is_last;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, a = blockIdx.x;
+    {
+        const double* __restrict__ row = sp.partials + (size_t)a * sp.nblocks;
+        double x = 0.0;
+        for (int b = threadIdx.x; b < sp.nblocks; b += SOLVE_THREADS) x += row[b];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
+        if (lane == 0) wsum[w] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double x = wsum[0];
+        for (int k = 1; k < SOLVE_THREADS / WAVE; k++) x += wsum[k];
+        __hip_atomic_store(sp.totals + a, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const unsigned t = atomicAdd(sp.ticket, 1u);
+        is_last = (t == (unsigned)(NSUM - 1));
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (threadIdx.x < NSUM) tot[threadIdx.x] = __hip_atomic_load(sp.totals + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    *sp.ticket = 0u;                                      // ready for the next launch on this stream
+    if (sp.sums_out) for (int a = 0; a < NSUM; a++) sp.sums_out[a] = tot[a];
+    PoseState* ps = sp.ps;
+    const double n = tot[SUM_N];
+    if (sp.phase == 0) {
+        // means of the valid pairs (utils.h:136-145 computes them as fp32 running sums; here fp64 sums rounded once)
+        float ms[3] = {0, 0, 0}, md[3] = {0, 0, 0};
+        if (n > 0) for (int k = 0; k < 3; k++) { ms[k] = (float)(tot[SUM_S + k] / n); md[k] = (float)(tot[SUM_D + k] / n); }
+        for (int k = 0; k < 3; k++) { ps->mean_s[k] = ms[k]; ps->mean_d[k] = md[k]; }
+    }
+    if (!sp.update_pose) return;
+    if (sp.metric == ICP_METRIC_SYMMETRIC && sp.phase == 0) return;      // wait for the second pass
+    int status = ICP_OK;
+    float dT[16];
+    for (int i = 0; i < 16; i++) dT[i] = (i % 5 == 0) ? 1.f : 0.f;
+    if (!(n > 0)) {
+        status = ICP_ERR_NO_CORRESPONDENCES;
+    } else if (sp.metric == ICP_METRIC_POINT_TO_PLANE) {
+        double x[6];
+        solve_normal_svd(tot + SUM_M, x);
+        const float al = (float)x[0], be = (float)x[1], ga = (float)x[2];       // ICPOptimizer.h:768
+        const float ca = (float)cos((double)al), sa = (float)sin((double)al);
+        const float cb = (float)cos((double)be), sb = (float)sin((double)be);
+        const float cg = (float)cos((double)ga), sg = (float)sin((double)ga);
+        const float Rx[9] = {1, 0, 0, 0, ca, -sa, 0, sa, ca}, Ry[9] = {cb, 0, sb, 0, 1, 0, -sb, 0, cb}, Rz[9] = {cg, -sg, 0, sg, cg, 0, 0, 0, 1};
+        float Rxy[9], R[9];
+        mat3_mul_f32(Rx, Ry, Rxy); mat3_mul_f32(Rxy, Rz, R);                   // :771-773
+        const float t[3] = {(float)x[3], (float)x[4], (float)x[5]};
+        set_pose_f32(dT, R, t);
+    } else if (sp.metric == ICP_METRIC_POINT_TO_POINT) {
+        // A = sum_i (d_i - dm)(w_i (s_i - sm))^T expanded in moments (ProcrustesAligner.h:50-55)
+        const double* m = tot + SUM_M;
+        const float msf[3] = {ps->mean_s[0], ps->mean_s[1], ps->mean_s[2]}, mdf[3] = {ps->mean_d[0], ps->mean_d[1], ps->mean_d[2]};
+        double A[9];
+        for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++)
+            A[j * 3 + k] = m[7 + j * 3 + k] - m[4 + j] * (double)msf[k] - (double)mdf[j] * m[1 + k] + m[0] * (double)mdf[j] * (double)msf[k];
+        double Rd[9]; float R[9];
+        procrustes_rotation(A, Rd);
+        for (int i = 0; i < 9; i++) R[i] = (float)Rd[i];
+        const float tr[3] = {mdf[0] - msf[0], mdf[1] - msf[1], mdf[2] - msf[2]};     // ProcrustesAligner.h:70
+        float t[3];
+        for (int r = 0; r < 3; r++) {
+            const float Rt = R[r * 3] * tr[0] + (R[r * 3 + 1] * tr[1] + R[r * 3 + 2] * tr[2]);
+            const float Rm = R[r * 3] * mdf[0] + (R[r * 3 + 1] * mdf[1] + R[r * 3 + 2] * mdf[2]);
+            t[r] = (Rt - Rm) + mdf[r];                                             // ProcrustesAligner.h:26
+        }
+        set_pose_f32(dT, R, t);
+    } else {
+        // symmetric: M = A^T A + lambda^2 I, FullPivLU (ICPOptimizer.h:858-868)
+        double M[36], g[6], x[6];
+        int q = 0;
+        for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { M[a * 6 + c] = tot[SUM_M + q]; M[c * 6 + a] = tot[SUM_M + q]; q++; }
+        for (int a = 0; a < 6; a++) g[a] = tot[SUM_M + 21 + a];
+        const float lambda = 0.0001f; const float l2 = lambda * lambda;
+        for (int a = 0; a < 6; a++) M[a * 6 + a] += (double)l2;
+        solve_fullpiv_lu6(M, g, x);
+        const float at[3] = {(float)x[0], (float)x[1], (float)x[2]}, tt[3] = {(float)x[3], (float)x[4], (float)x[5]};
+        const float tan_theta = sqrtf(at[0] * at[0] + (at[1] * at[1] + at[2] * at[2]));     // :878
+        const float ax[3] = {at[0] / tan_theta, at[1] / tan_theta, at[2] / tan_theta};      // :879
+        const float sin_theta = (float)((double)tan_theta / sqrt(1.0 + (double)(tan_theta * tan_theta)));   // :884
+        const float cos_theta = sin_theta / tan_theta;                                      // :885
+        const float t[3] = {tt[0] * cos_theta, tt[1] * cos_theta, tt[2] * cos_theta};
+        const float K[9] = {0, -ax[2], ax[1], ax[2], 0, -ax[0], -ax[1], ax[0], 0};
+        float Ks[9], KK[9], Rod[9];
+        const float omc = 1 - cos_theta;
+        for (int i = 0; i < 9; i++) Ks[i] = omc * K[i];
+        mat3_mul_f32(Ks, K, KK);
+        for (int i = 0; i < 9; i++) Rod[i] = ((i % 4 == 0) ? 1.f : 0.f) + (sin_theta * K[i] + KK[i]);   // utils.h:171-176
+        const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, zero[3] = {0, 0, 0};
+        const float md[3] = {ps->mean_d[0], ps->mean_d[1], ps->mean_d[2]}, nms[3] = {-ps->mean_s[0], -ps->mean_s[1], -ps->mean_s[2]};
+        float Tm[16], Tt[16], Ts[16], Rm[16], t1[16], t2[16];
+        set_pose_f32(Tm, I3, md); set_pose_f32(Tt, I3, t); set_pose_f32(Ts, I3, nms); set_pose_f32(Rm, Rod, zero);
+        mat4_mul_f32(Tm, Rm, t1); mat4_mul_f32(t1, Tt, t2); mat4_mul_f32(t2, Rm, t1); mat4_mul_f32(t1, Ts, dT);   // :894-895
+    }
+    if (status == ICP_OK) {
+        float np[16];
+        mat4_mul_f32(dT, ps->pose, np);                                           // ICPOptimizer.h:614-620
+        for (int i = 0; i < 16; i++) ps->pose[i] = np[i];
+        normal_matrix_from_pose(ps->pose, ps->nmat);
+    }
+    if (sp.stats) {
+        sp.stats->n_src = sp.n_src;
+        sp.stats->n_valid = (int)n;
+        for (int i = 0; i < 16; i++) sp.stats->pose[i] = ps->pose[i];
+        sp.stats->rmse = -1.f;
+        sp.stats->benchmark_error = -1.f;
+        sp.stats->status = status;
+    }
+}
