@@ -445,6 +445,22 @@ __device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, cons
     if (kp.d2_out) kp.d2_out[k] = best;
 }
 
+// The tree walk proper for query p, starting from the seed (best, bi, bpos); returns the lower bound on the distance to every
+// target other than the winner.  NT = threads of the block (layout of the LDS stacks).
+template <int DIM, int NT>
+__device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* p, float& best, int& bi, int& bpos, uint2* __restrict__ lbq, int tid) {
+    f2 p2[DIM];
+#pragma unroll
+    for (int q = 0; q < DIM; q++) { p2[q].x = p[q]; p2[q].y = p[q]; }
+    float best2 = FLT_MAX, minlb = FLT_MAX;
+    unsigned int touched = 0u;
+    if (ICP_PREFETCH_PATH && bpos >= 0) touched = quad_prefetch_path<DIM>(bv, bpos >> 3);
+    QuadState st; st.L = 0; st.idx = 0; st.pending = 0ull; st.alive = true;
+    quad_run<DIM>(bv, p2, st, best, bi, bpos, best2, minlb, lbq, tid, NT);
+    asm volatile("" ::"v"(touched));
+    return sqrtf(fminf(best2, minlb)) * 0.999999f;
+}
+
 template <int DIM>
 __device__ __forceinline__ void knn_bvh_query(const KnnParams& kp, const BvhViewT<DIM>& bv, int k, uint2* __restrict__ lbq, int tid,
                                               float& best, int& bi, int& bpos) {
@@ -453,18 +469,7 @@ __device__ __forceinline__ void knn_bvh_query(const KnnParams& kp, const BvhView
     best = FLT_MAX; bi = -1; bpos = -1;
     float lb_others = 0.f;               // lower bound on the (real) distance from p to every target except bi
     if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
-        if (!knn_try_verify<DIM>(kp, bv, k, p, best, bi, bpos, lb_others)) {
-            f2 p2[DIM];
-#pragma unroll
-            for (int q = 0; q < DIM; q++) { p2[q].x = p[q]; p2[q].y = p[q]; }
-            float best2 = FLT_MAX, minlb = FLT_MAX;
-            unsigned int touched = 0u;
-            if (ICP_PREFETCH_PATH && bpos >= 0) touched = quad_prefetch_path<DIM>(bv, bpos >> 3);
-            QuadState st; st.L = 0; st.idx = 0; st.pending = 0ull; st.alive = true;
-            quad_run<DIM>(bv, p2, st, best, bi, bpos, best2, minlb, lbq, tid, BVH_THREADS);
-            asm volatile("" ::"v"(touched));
-            lb_others = sqrtf(fminf(best2, minlb)) * 0.999999f;
-        }
+        if (!knn_try_verify<DIM>(kp, bv, k, p, best, bi, bpos, lb_others)) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lbq, tid);
     }
     knn_store_state<DIM>(kp, k, p, best, bpos, lb_others);
 }

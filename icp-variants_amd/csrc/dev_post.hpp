@@ -150,14 +150,18 @@ struct PostParams {
 // Weight, reject and filter ONE correspondence (source position k, match m after matching, matched target point d / normal nt /
 // colour tcol): the body of applyWeights / pruneCorrespondences / the validity filter.  Writes the final Match back; returns
 // whether the pair enters the system, with the transformed source point and the weight.  post_core adds the system build.
+template <bool HAVE_S = false>
 __device__ __forceinline__ bool post_eval(const PostParams& pp, int k, icp_match_t m, float d0, float d1, float d2, float nt0, float nt1, float nt2, uint32_t tcol,
-                                          float& s0, float& s1, float& s2, float& w) {
+                                          float& s0, float& s1, float& s2, float& w, float rn0 = 0.f, float rn1 = 0.f, float rn2 = 0.f) {
     const float* __restrict__ P = pp.ps->pose;
     const float* __restrict__ N = pp.ps->nmat;
     const int i = pp.sel ? pp.sel[k] : k;
     float ns0, ns1, ns2;
-    xform_point(P, pp.sx[i], pp.sy[i], pp.sz[i], s0, s1, s2);
-    xform_normal(N, pp.snx[i], pp.sny[i], pp.snz[i], ns0, ns1, ns2);
+    if (!HAVE_S) {                                         // HAVE_S: the matcher passes the transformed point and the raw source normal
+        xform_point(P, pp.sx[i], pp.sy[i], pp.sz[i], s0, s1, s2);
+        rn0 = pp.snx[i]; rn1 = pp.sny[i]; rn2 = pp.snz[i];
+    }
+    xform_normal(N, rn0, rn1, rn2, ns0, ns1, ns2);
     const bool fin_sd = finite3(s0, s1, s2) && finite3(d0, d1, d2);
     // ---- applyWeights, weighting.h:44-90 ----
     if (pp.weighting != ICP_WEIGHT_CONSTANT) {
@@ -240,67 +244,142 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(const PostParams pp) {
 // has exactly one pair, so the 34 sums are not accumulated in registers first: every value is produced, folded 64 -> 16 lanes
 // with two shuffles and parked in LDS right away (groups separated by scheduling barriers), which keeps the kernel at the
 // register budget of the walk.  Block partials keep the fixed-order reduction contract.
-__device__ __forceinline__ void fold_store(double x, double* lds, int a, int lane, int w) {
-    x += __shfl_down(x, 32, WAVE);
-    x += __shfl_down(x, 16, WAVE);
-    if (lane < 16) lds[(w * 34 + a) * 17 + lane] = x;
-}
-template <int A, int END>
-__device__ __forceinline__ void fold_row_slots(const RowTerms& R, bool valid, double* lds, int lane, int w) {
-    if constexpr (A < END) {
-        fold_store(valid ? row_slot<A>(R) : 0.0, lds, SUM_M + A, lane, w);
-        fold_row_slots<A + 1, END>(R, valid, lds, lane, w);
+// N values at a time, stage by stage (all shuffles of a stage in flight together: the cross-lane permutes have ~100 cycles of
+// latency each, a value-by-value chain would expose 2 x 34 of them per wave).
+template <int N>
+__device__ __forceinline__ void fold_store_n(double (&x)[N], double* lds, int a0, int lane, int w) {
+    double y[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) y[i] = __shfl_down(x[i], 32, WAVE);
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] += y[i];
+#pragma unroll
+    for (int i = 0; i < N; i++) y[i] = __shfl_down(x[i], 16, WAVE);
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] += y[i];
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < N; i++) lds[(w * 34 + a0 + i) * 17 + lane] = x[i];
     }
+}
+template <int A, int N, int I = 0>
+__device__ __forceinline__ void row_slots_n(const RowTerms& R, bool valid, double (&x)[N]) {
+    if constexpr (I < N) { x[I] = valid ? row_slot<A + I>(R) : 0.0; row_slots_n<A, N, I + 1>(R, valid, x); }
+}
+template <int A, int N>
+__device__ __forceinline__ void fold_row_slots(const RowTerms& R, bool valid, double* lds, int lane, int w) {
+    double x[N];
+    row_slots_n<A, N>(R, valid, x);
+    fold_store_n<N>(x, lds, SUM_M + A, lane, w);
 }
 template <int DIM>
 __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {
     extern __shared__ uint2 bvh_lbq[];                    // [Lq][BVH_THREADS] pending-sibling bounds; reused by the reduction
     constexpr int NW = BVH_THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int k = knn_bvh_lane_query(kp, qorder, tid);
+    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS + tid;
+    const int k = (t < kp.n) ? (qorder ? qorder[t] : t) : -1;      // (the work-list second pass never runs fused)
     bool valid = false;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, wt = 0.f;
     if (k >= 0) {
-        float best; int bi, bpos;
-        knn_bvh_query<DIM>(kp, bv, k, bvh_lbq, tid, best, bi, bpos);
+        // ---- front end.  Everything that depends only on the query index is requested in ONE batch (point, normal, previous
+        // neighbour, search state), then the neighbour's record: two memory round trips before the verify test instead of
+        // one per array -- in the late iterations, where almost no query walks, those round trips ARE the kernel.
+        const int i = kp.sel ? kp.sel[k] : k;
+        float p[DIM];
+        const float r0 = kp.sx[i], r1 = kp.sy[i], r2 = kp.sz[i];
+        if (DIM == 6) { p[3 % DIM] = kp.scr[i]; p[4 % DIM] = kp.scg[i]; p[5 % DIM] = kp.scb[i]; }
+        const float rn0 = pp.snx[i], rn1 = pp.sny[i], rn2 = pp.snz[i];
+        const bool seeded = kp.use_prev != 0, inc = kp.incremental && seeded;
+        const int q0 = seeded ? kp.nn_raw[k] : -1;
+        float4 st; st.x = 0.f; st.y = 0.f; st.z = 0.f; st.w = 0.f;
+        if (inc) st = kp.qstate[k];
+        xform_point(kp.ps->pose, r0, r1, r2, p[0], p[1], p[2]);
+        float best = FLT_MAX, lb_others = 0.f; int bi = -1, bpos = -1;
+        float4 ra, rb; ra.x = 0.f; ra.y = 0.f; ra.z = 0.f; ra.w = 0.f; rb = ra;
+        if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
+            bool verified = false;
+            if (q0 >= 0) {                                 // seed_from_previous + knn_try_verify, on the batched loads
+                float t[DIM]; int j0;
+                if (DIM == 3) { ra = *(const float4*)(bv.recs + q0); rb = *((const float4*)(bv.recs + q0) + 1); t[0] = ra.x; t[1] = ra.y; t[2] = ra.z; j0 = __float_as_int(ra.w); }
+                else {
+                    const BvhLeafT<DIM>* lf = bv.leaves + (q0 >> 3);
+#pragma unroll
+                    for (int q = 0; q < DIM; q++) t[q] = lf->c[q][q0 & 7];
+                    j0 = lf->idx[q0 & 7];
+                }
+                float d = 0.f;
+#pragma unroll
+                for (int q = 0; q < DIM; q++) { const float e = p[q] - t[q]; d = (q == 0) ? e * e : d + e * e; }
+                if (d < best) { best = d; bi = j0; bpos = q0; }
+                if (inc && bi >= 0) {
+                    const float ex = p[0] - st.x, ey = p[1] - st.y, ez = p[2] - st.z;
+                    const float delta = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.000001f + 1e-30f;
+                    const float lbn = (st.w - delta) * 0.999999f;
+                    if (sqrtf(best) * 1.000001f < lbn) { lb_others = lbn; verified = true; }
+                }
+            }
+            if (!verified) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, bvh_lbq, tid);
+        }
+        knn_store_state<DIM>(kp, k, p, best, bpos, lb_others);
         icp_match_t m;
         if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
         if (m.idx < 0) pp.matches[k] = m;
         else {
-            const float4 ra = *(const float4*)(bv.recs + bpos), rb = *((const float4*)(bv.recs + bpos) + 1);      // one 32-byte record
+            if (DIM != 3 || bpos != q0) { ra = *(const float4*)(bv.recs + bpos); rb = *((const float4*)(bv.recs + bpos) + 1); }      // one 32-byte record
             d0 = ra.x; d1 = ra.y; d2 = ra.z; n0 = rb.x; n1 = rb.y; n2 = rb.z;
-            valid = post_eval(pp, k, m, d0, d1, d2, n0, n1, n2, __float_as_uint(rb.w), s0, s1, s2, wt);
+            s0 = p[0]; s1 = p[1]; s2 = p[2];
+            valid = post_eval<true>(pp, k, m, d0, d1, d2, n0, n1, n2, __float_as_uint(rb.w), s0, s1, s2, wt, rn0, rn1, rn2);
         }
     }
     __syncthreads();                                      // the traversal stacks are dead: reuse LDS for the reduction
     double* lds = (double*)bvh_lbq;
-    fold_store(valid ? 1.0 : 0.0, lds, SUM_N, lane, w);
-    fold_store(valid ? (double)s0 : 0.0, lds, SUM_S, lane, w); fold_store(valid ? (double)s1 : 0.0, lds, SUM_S + 1, lane, w); fold_store(valid ? (double)s2 : 0.0, lds, SUM_S + 2, lane, w);
-    fold_store(valid ? (double)d0 : 0.0, lds, SUM_D, lane, w); fold_store(valid ? (double)d1 : 0.0, lds, SUM_D + 1, lane, w); fold_store(valid ? (double)d2 : 0.0, lds, SUM_D + 2, lane, w);
+    {   // the count is an integer: one ballot per wave, stored as lane 0's "partial" (the other 15 are zero)
+        const unsigned long long vm = __ballot(valid);
+        if (lane < 16) lds[(w * 34 + SUM_N) * 17 + lane] = (lane == 0) ? (double)__popcll(vm) : 0.0;
+    }
+    if (pp.metric == ICP_METRIC_POINT_TO_PLANE) {
+        // the sums of s and d feed only the means (point-to-point / symmetric): not needed here, their slots stay zero
+        if (lane < 16) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) lds[(w * 34 + SUM_S + q) * 17 + lane] = 0.0;
+        }
+    } else {
+        double x[6] = {valid ? (double)s0 : 0.0, valid ? (double)s1 : 0.0, valid ? (double)s2 : 0.0,
+                       valid ? (double)d0 : 0.0, valid ? (double)d1 : 0.0, valid ? (double)d2 : 0.0};
+        fold_store_n<6>(x, lds, SUM_S, lane, w);          // SUM_S.., SUM_D.. are slots 1..6
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (pp.metric == ICP_METRIC_POINT_TO_PLANE) {
         RowTerms R;
         build_rows(0, s0, s1, s2, d0, d1, d2, n0, n1, n2, wt, R);
         fold_row_slots<0, 7>(R, valid, lds, lane, w);   __builtin_amdgcn_sched_barrier(0);
-        fold_row_slots<7, 14>(R, valid, lds, lane, w);  __builtin_amdgcn_sched_barrier(0);
-        fold_row_slots<14, 21>(R, valid, lds, lane, w); __builtin_amdgcn_sched_barrier(0);
-        fold_row_slots<21, 27>(R, valid, lds, lane, w);
+        fold_row_slots<7, 7>(R, valid, lds, lane, w);   __builtin_amdgcn_sched_barrier(0);
+        fold_row_slots<14, 7>(R, valid, lds, lane, w);  __builtin_amdgcn_sched_barrier(0);
+        fold_row_slots<21, 6>(R, valid, lds, lane, w);
     } else {                                              // point-to-point moments (see post_core)
         const double wd = (double)wt;
         const double ws[3] = {wd * s0, wd * s1, wd * s2};
         const float dd[3] = {d0, d1, d2};
-        fold_store(valid ? wd : 0.0, lds, SUM_M, lane, w);
-#pragma unroll
-        for (int q = 0; q < 3; q++) fold_store(valid ? ws[q] : 0.0, lds, SUM_M + 1 + q, lane, w);
-#pragma unroll
-        for (int q = 0; q < 3; q++) fold_store(valid ? wd * dd[q] : 0.0, lds, SUM_M + 4 + q, lane, w);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-#pragma unroll
-            for (int q = 0; q < 3; q++) fold_store(valid ? (double)dd[j] * ws[q] : 0.0, lds, SUM_M + 7 + j * 3 + q, lane, w);
+        {
+            double x[7] = {valid ? wd : 0.0, valid ? ws[0] : 0.0, valid ? ws[1] : 0.0, valid ? ws[2] : 0.0,
+                           valid ? wd * dd[0] : 0.0, valid ? wd * dd[1] : 0.0, valid ? wd * dd[2] : 0.0};
+            fold_store_n<7>(x, lds, SUM_M, lane, w);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            double x[9];
 #pragma unroll
-        for (int q = 16; q < 27; q++) fold_store(0.0, lds, SUM_M + q, lane, w);
+            for (int j = 0; j < 3; j++) {
+#pragma unroll
+                for (int q = 0; q < 3; q++) x[j * 3 + q] = valid ? (double)dd[j] * ws[q] : 0.0;
+            }
+            fold_store_n<9>(x, lds, SUM_M + 7, lane, w);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int q = 16; q < 27; q++) lds[(w * 34 + SUM_M + q) * 17 + lane] = 0.0;
+        }
     }
     __syncthreads();
     if (tid < 34) {
