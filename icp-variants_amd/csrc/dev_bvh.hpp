@@ -131,6 +131,90 @@ __global__ void k_bvh_level_keys(const CoordPtrs<DIM> cp, const int* __restrict_
     keys[i] = ((unsigned long long)(unsigned int)node << 32) | ordered_bits(c);
 }
 
+// The lower levels of the build in one kernel.  Once a node's slice is <= 2048 points the remaining levels only permute
+// points INSIDE that slice, so a block takes 2048 consecutive positions into LDS and runs all of them there: per level the
+// boxes of the slices (shuffle tree + at most 4 wave boxes), the widest axis, and a bitonic sort of every slice on
+// (ordered coordinate bits, position) -- the position makes the keys unique and reproduces the stable order of the global
+// radix sort, so the tree is exactly the one the level-by-level build produces.  Replaces 8 global sorts (~120 us each).
+constexpr int BLV_POINTS = 2048, BLV_THREADS = 256, BLV_PER = BLV_POINTS / BLV_THREADS;
+template <int DIM>
+__global__ __launch_bounds__(BLV_THREADS) void k_bvh_block_levels(const CoordPtrs<DIM> cp, const int* __restrict__ perm_in, int n_valid, int first_shift /* <= 11 */,
+                                                                  int* __restrict__ perm_out) {
+    __shared__ unsigned long long keys[BLV_POINTS];
+    __shared__ int vals[BLV_POINTS];
+    __shared__ unsigned int wbox[BLV_THREADS / WAVE][2 * DIM];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int base = blockIdx.x * BLV_POINTS;
+#pragma unroll
+    for (int q = 0; q < BLV_PER; q++) { const int pos = tid * BLV_PER + q, gi = base + pos; vals[pos] = gi < n_valid ? perm_in[gi] : -1; }
+    __syncthreads();
+    for (int sh = first_shift; sh >= 4; sh--) {            // slices of 2^sh positions; the last level splits 16 -> two leaves of 8
+        const int S = 1 << sh, g = S / BLV_PER;             // g threads per slice (2 .. 256), aligned
+        unsigned int lo[DIM], hi[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; k++) { lo[k] = 0xFFFFFFFFu; hi[k] = 0u; }
+        for (int q = 0; q < BLV_PER; q++) {
+            const int j = vals[tid * BLV_PER + q];
+            if (j >= 0) {
+#pragma unroll
+                for (int k = 0; k < DIM; k++) { const unsigned int o = ordered_bits(cp.c[k][j]); lo[k] = min(lo[k], o); hi[k] = max(hi[k], o); }
+            }
+        }
+        for (int off = 1; off < g && off < WAVE; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < DIM; k++) { lo[k] = min(lo[k], (unsigned int)__shfl_xor((int)lo[k], off, WAVE)); hi[k] = max(hi[k], (unsigned int)__shfl_xor((int)hi[k], off, WAVE)); }
+        }
+        if (g > WAVE) {                                    // slice spans 2 or 4 waves
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < DIM; k++) { wbox[w][k] = lo[k]; wbox[w][DIM + k] = hi[k]; }
+            }
+            __syncthreads();
+            const int nw = g / WAVE, w0 = w & ~(nw - 1);
+            for (int ww = w0; ww < w0 + nw; ww++) {
+#pragma unroll
+                for (int k = 0; k < DIM; k++) { lo[k] = min(lo[k], wbox[ww][k]); hi[k] = max(hi[k], wbox[ww][DIM + k]); }
+            }
+        }
+        int axis = 0; float ext = -1.f;
+#pragma unroll
+        for (int k = 0; k < DIM; k++) {
+            // from_ordered_bits spelled with ^ instead of & 0x7FFFFFFF: the other spelling crashes the gfx950 instruction selector here
+            const unsigned int uh = hi[k], ul = lo[k];
+            const float fh = __uint_as_float((uh & 0x80000000u) ? (uh ^ 0x80000000u) : ~uh), fl = __uint_as_float((ul & 0x80000000u) ? (ul ^ 0x80000000u) : ~ul);
+            const float e = fh - fl;
+            if (e > ext) { ext = e; axis = k; }
+        }
+        for (int q = 0; q < BLV_PER; q++) {
+            const int pos = tid * BLV_PER + q, j = vals[pos];
+            unsigned long long key = ~0ull;
+            if (j >= 0) {
+                float c = cp.c[0][j];
+#pragma unroll
+                for (int k = 1; k < DIM; k++) c = (axis == k) ? cp.c[k][j] : c;      // (selecting the plane POINTER instead crashes the gfx950 instruction selector)
+                key = ((unsigned long long)ordered_bits(c) << 32) | (unsigned int)pos;
+            }
+            keys[pos] = key;
+        }
+        __syncthreads();
+        for (int k = 2; k <= S; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+                for (int pp = 0; pp < BLV_POINTS / 2 / BLV_THREADS; pp++) {
+                    const int idx = tid + BLV_THREADS * pp;
+                    const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1)), ip = i + j;
+                    const bool asc = ((i & k) == 0) || (k == S);
+                    const unsigned long long a = keys[i], b = keys[ip];
+                    if ((a > b) == asc) { keys[i] = b; keys[ip] = a; const int va = vals[i]; vals[i] = vals[ip]; vals[ip] = va; }
+                }
+                __syncthreads();
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < BLV_PER; q++) { const int pos = tid * BLV_PER + q, gi = base + pos; if (gi < n_valid) perm_out[gi] = vals[pos]; }
+}
+
 template <int DIM>
 __global__ void k_bvh_gather(const CoordPtrs<DIM> cp, const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ nz, const uint32_t* __restrict__ rgba,
                              const int* __restrict__ sorted_idx, int n_valid, int n_slots, BvhLeafT<DIM>* __restrict__ leaves, TgtRec* __restrict__ recs) {

@@ -66,6 +66,7 @@ struct icp_ctx {
     bool owns_stream = false;
     int stage_timing = 1;                // icp_set_stage_timing: 0 none, 1 every iteration, N > 1 every Nth iteration (scaled)
     unsigned timing_phase = 0;           // rotates the sampled iterations from run to run
+    bool block_levels = true;            // BVH build: levels with slices <= 2048 points in one LDS kernel (ICP_HIP_BLOCK_LEVELS=0: global sorts)
     bool trace = false;                  // ICP_HIP_TRACE=1: per-iteration stage times on stderr
     bool two_pass = false;               // incremental k-NN as verify pass + packed tree-walk pass (ICP_HIP_TWO_PASS=1; measured slower: walk latency is exposed)
     bool fuse_post = true;               // BVH matcher runs weight / reject / accumulate as its epilogue (ICP_HIP_FUSE_POST=0 disables)
@@ -234,6 +235,11 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
         for (int d = 0; d < depth; d++) {
             // segment (node) size at level d in points: BVH_LEAF * Lp / 2^d  = 1 << seg_shift
             int seg_shift = 0; { long long seg = (long long)BVH_LEAF * b.Lp >> d; while ((1LL << seg_shift) < seg) seg_shift++; }
+            if (c->block_levels && seg_shift <= 11) {        // slices of <= 2048 points: all remaining levels inside LDS, one launch
+                hipLaunchKernelGGL(k_bvh_block_levels<DIM>, dim3((nv + BLV_POINTS - 1) / BLV_POINTS), dim3(BLV_THREADS), 0, c->stream, cp, perm, nv, seg_shift, perm2);
+                int* t = perm; perm = perm2; perm2 = t;
+                break;
+            }
             const int n_nodes = 1 << d;
             if (seg_shift >= 6) {            // wave-aligned segments: per-wave boxes, then one wave per node folds them
                 const int n_waves = (nv + 63) / 64;
@@ -541,6 +547,7 @@ int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out) {
     memset(&c->timing, 0, sizeof(c->timing));
     if (hipSetDevice(device) != hipSuccess) { delete c; return ICP_ERR_HIP; }
     { const char* e = getenv("ICP_HIP_FUSE_POST"); if (e && e[0] == '0') c->fuse_post = false; }
+    { const char* e = getenv("ICP_HIP_BLOCK_LEVELS"); if (e && e[0] == '0') c->block_levels = false; }
     { const char* e = getenv("ICP_HIP_TRACE"); if (e && e[0] == '1') c->trace = true; }
     { const char* e = getenv("ICP_HIP_TWO_PASS"); if (e && e[0] == '1') c->two_pass = true; }
     { const char* e = getenv("ICP_HIP_STAGE_EVENTS"); if (e && e[0] >= '0' && e[0] <= '9') c->stage_timing = atoi(e); }
