@@ -1,0 +1,111 @@
+"""The full ICP pipeline with the product's default matcher for large clouds -- the exact BVH backend with the fused
+weight / reject / accumulate epilogue, Morton-sorted source levels, incremental search and the lane-parallel solve --
+against the oracle and the golden bunny trajectories (the same checks test_gpu_parity.py runs on the scan backend)."""
+import numpy as np
+import pytest
+from test_gpu_parity import make_ctx, rand_pose, POSE_TOL, small_pair  # noqa: F401  (small_pair is a fixture)
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+LBVH = 1
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("weighting", [0, 1, 2, 3])
+def test_single_iteration_pose_lbvh(gpu_ctx_factory, orc, small_pair, metric, weighting):
+    """One iteration: identical valid count, delta pose within 1e-5 of both oracle flavours, every weighting (3 = colours)."""
+    p = small_pair
+    c = make_ctx(gpu_ctx_factory, (p["tgt_pts"], p["tgt_nrm"], p["tgt_rgba"]), (p["src_pts"], p["src_nrm"], p["src_rgba"]),
+                 max_distance=0.3, weighting=weighting, metric=metric, knn_backend=LBVH)
+    T = rand_pose(20 + metric, 0.02, 0.03)
+    pose, st = c.iterate(T)
+    for mode in (1, 0):
+        prm = orc.make_params(metric=metric, weighting=weighting, n_iterations=1, max_distance=0.3, solver_mode=mode)
+        po, mo, nvo, _, _ = orc.iterate(prm, p["src_pts"], p["src_nrm"], p["src_rgba"], p["tgt_pts"], p["tgt_nrm"], p["tgt_rgba"], T)
+        assert st["n_valid"] == nvo
+        assert np.abs(pose - po).max() < POSE_TOL, (mode, np.abs(pose - po).max())
+    assert st["status"] == 0 and np.array_equal(st["pose"], pose)
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("weighting,multires,rejection", [(0, 0, 1), (1, 0, 1), (2, 0, 1), (0, 1, 1)])
+def test_bunny_full_run_vs_golden_lbvh(gpu_ctx_factory, bunny, bunny_oracle, metric, weighting, multires, rejection):
+    """Data/bunny_experiments.csv linear rows, 20 iterations, on the BVH backend: final pose within 1e-5 of both oracle
+    flavours, per-iteration sizes identical to the golden trajectories."""
+    from conftest import pose_error
+    from icp_amd import binding
+    opt = binding.LinearICPOptimizer(0)
+    opt.setMatchingMethod(0); opt.setMatchingMaxDistance(0.0003); opt.setKnnBackend(LBVH)
+    opt.setMetric(metric); opt.setNbOfIterations(20); opt.setWeightingMethod(weighting); opt.enableMultiResolution(bool(multires))
+    pose, recs = opt.estimatePose(dict(pts=bunny["src_pts"], nrm=bunny["src_nrm"], rgba=bunny["src_rgba"]),
+                                  dict(pts=bunny["tgt_pts"], nrm=bunny["tgt_nrm"], rgba=bunny["tgt_rgba"]), np.eye(4))
+    key = "m%d_w%d_r%d" % (metric, weighting, multires)
+    assert [r["n_src"] for r in recs] == bunny_oracle[key + "_mode1_nsrc"].tolist()
+    assert [r["n_valid"] for r in recs][-1] == bunny_oracle[key + "_mode1_nvalid"][-1]
+    for mode in (1, 0):
+        ang, tr = pose_error(pose, bunny_oracle[key + "_mode%d_poses" % mode][-1])
+        assert ang < POSE_TOL and tr < POSE_TOL, (mode, ang, tr)
+    opt.ctx.close()
+
+
+@pytest.mark.parametrize("metric,multires", [(0, 0), (1, 0), (2, 0), (1, 1)])
+def test_random_selection_run_matches_oracle_lbvh(gpu_ctx_factory, orc, bunny, metric, multires):
+    from conftest import pose_error
+    from icp_amd import binding
+    opt = binding.LinearICPOptimizer(0)
+    opt.setMatchingMaxDistance(0.0003); opt.setMetric(metric); opt.setNbOfIterations(20); opt.enableMultiResolution(bool(multires)); opt.setKnnBackend(LBVH)
+    opt.setSelectionMethod(1, 0.5, seed=1234)
+    pose, recs = opt.estimatePose(dict(pts=bunny["src_pts"], nrm=bunny["src_nrm"]), dict(pts=bunny["tgt_pts"], nrm=bunny["tgt_nrm"]), np.eye(4))
+    prm = orc.make_params(metric=metric, multires=multires, n_iterations=20, max_distance=0.0003, solver_mode=1, selection=1, selection_proba=0.5, selection_seed=1234)
+    po, ro = orc.estimate_pose(prm, bunny["src_pts"], bunny["src_nrm"], None, bunny["tgt_pts"], bunny["tgt_nrm"], None, np.eye(4))
+    assert [r["n_src"] for r in recs] == [r["n_src"] for r in ro]
+    assert [r["n_valid"] for r in recs][:5] == [r["n_valid"] for r in ro][:5]
+    ang, tr = pose_error(pose, po)
+    assert ang < POSE_TOL and tr < POSE_TOL
+    opt.ctx.close()
+
+
+def test_no_correspondences_and_nonfinite_sources_lbvh(gpu_ctx_factory, bunny):
+    """Nothing within reach -> status code, pose untouched; NaN / inf source points and normals are skipped, not propagated."""
+    from icp_amd import binding
+    far = bunny["src_pts"] + f32(100.0)
+    c = make_ctx(gpu_ctx_factory, (bunny["tgt_pts"], bunny["tgt_nrm"], None), (far, bunny["src_nrm"], None), max_distance=0.0003, metric=1, n_iterations=3, knn_backend=LBVH)
+    pose, recs, rc = c.run(np.eye(4), check=False)
+    assert rc == binding.ERR_NO_CORRESPONDENCES
+    assert all(r["n_valid"] == 0 and r["status"] == binding.ERR_NO_CORRESPONDENCES for r in recs)
+    assert np.array_equal(pose, np.eye(4, dtype=f32))
+    src = bunny["src_pts"].copy(); nrm = bunny["src_nrm"].copy()
+    src[5] = np.nan; src[77, 1] = np.inf; nrm[200] = np.nan
+    poses = []
+    for backend in (0, LBVH):
+        c = make_ctx(gpu_ctx_factory, (bunny["tgt_pts"], bunny["tgt_nrm"], None), (src, nrm, None), max_distance=0.0003, metric=1, n_iterations=8, knn_backend=backend)
+        pose, recs, rc = c.run(np.eye(4))
+        assert rc == 0 and np.isfinite(pose).all()
+        poses.append((pose, [r["n_valid"] for r in recs]))
+    assert np.abs(poses[0][0] - poses[1][0]).max() < 1e-6 and poses[0][1] == poses[1][1]
+
+
+def test_context_reuse_across_pairs_lbvh(gpu_ctx_factory, orc, bunny, small_pair):
+    """New target / source on a live context: the index, the sorted source levels and the search state are rebuilt -- no stale
+    neighbours from the previous pair; reruns are bit-identical."""
+    c = gpu_ctx_factory()
+    c.params.max_distance = 0.3; c.params.metric = 1; c.params.n_iterations = 6; c.params.knn_backend = LBVH; c.push_params()
+    p = small_pair
+    c.set_target(p["tgt_pts"], p["tgt_nrm"]); c.set_source(p["src_pts"], p["src_nrm"])
+    a, ra, _ = c.run(np.eye(4))
+    c.params.max_distance = 0.0003; c.push_params()
+    c.set_target(bunny["tgt_pts"], bunny["tgt_nrm"]); c.set_source(bunny["src_pts"], bunny["src_nrm"])
+    m, d2 = c.match(np.eye(4))
+    mo, do = orc.knn3(bunny["src_pts"], bunny["tgt_pts"], 0.0003)
+    assert np.array_equal(m["idx"], mo["idx"])
+    mid, _, _ = c.run(np.eye(4))
+    c.params.max_distance = 0.3; c.push_params()
+    c.set_target(p["tgt_pts"], p["tgt_nrm"]); c.set_source(p["src_pts"], p["src_nrm"])
+    b, rb, _ = c.run(np.eye(4))
+    assert np.array_equal(a, b) and [r["n_valid"] for r in ra] == [r["n_valid"] for r in rb]
+    # same source, new target only
+    c.set_target(bunny["tgt_pts"], bunny["tgt_nrm"])
+    c.params.max_distance = 0.0003; c.push_params()
+    c.set_source(bunny["src_pts"], bunny["src_nrm"])
+    again, _, _ = c.run(np.eye(4))
+    assert np.array_equal(mid, again)
