@@ -405,7 +405,8 @@ __device__ __forceinline__ void quad_lb(const BvhQuadT<DIM>* __restrict__ nd, co
     }
 }
 
-__device__ __forceinline__ void quad_pop(QuadState& st, const uint2* __restrict__ lbq, int tid, int nthreads, float best, float& minlb) {
+// thr: prune threshold derived from the running best (see quad_run)
+__device__ __forceinline__ void quad_pop(QuadState& st, const uint2* __restrict__ lbq, int tid, int nthreads, float thr, float& minlb) {
     while (!st.alive && st.pending) {
         const int lv = (63 - __clzll((long long)st.pending)) >> 2;                // deepest level with pending children
         const unsigned int bits = (unsigned int)(st.pending >> (4 * lv)) & 0xFu;
@@ -413,7 +414,7 @@ __device__ __forceinline__ void quad_pop(QuadState& st, const uint2* __restrict_
         const float l0 = (bits & 1u) ? __uint_as_float(w.x << 16) : FLT_MAX, l1 = (bits & 2u) ? __uint_as_float(w.x & 0xFFFF0000u) : FLT_MAX;
         const float l2 = (bits & 4u) ? __uint_as_float(w.y << 16) : FLT_MAX, l3 = (bits & 8u) ? __uint_as_float(w.y & 0xFFFF0000u) : FLT_MAX;
         const float m = fminf(fminf(l0, l1), fminf(l2, l3));                      // truncated bounds: <= the true ones
-        if (m * 0.99999f > best) {                                               // the nearest pending sibling is out: so are the others
+        if (m > thr) {                                                           // the nearest pending sibling is out: so are the others
             minlb = fminf(minlb, m);
             st.pending &= ~(0xFull << (4 * lv));
         } else {
@@ -451,14 +452,17 @@ template <int DIM>
 __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const f2* p2, QuadState& st,
                                          float& best, int& bi, int& bpos, float& best2, float& minlb, uint2* __restrict__ lbq, int tid, int nthreads) {
     const int Lq = bv.Lq;
+    // A box is skipped when its lower bound exceeds thr = best * (1 + 2e-5) (clamped so that the +inf bound of an empty box is
+    // always skipped): that implies bound > best with margin, one multiply per change of `best` instead of one per box test.
+    float thr = fminf(best * 1.00002f, FLT_MAX);
     while (st.alive) {
         while (st.alive && st.L < Lq) {
             f2 l01, l23;
-            quad_lb<DIM>(bv.qnodes + ((0x5555555555555555ull & ((1ull << (2 * st.L)) - 1ull)) + (unsigned long long)st.idx), p2, l01, l23);
+            quad_lb<DIM>(bv.qnodes + ((0x55555555u & ((1u << (2 * st.L)) - 1u)) + (unsigned int)st.idx), p2, l01, l23);
             const float m = fminf(fminf(l01.x, l01.y), fminf(l23.x, l23.y));
-            const bool s0 = !(l01.x * 0.99999f > best), s1 = !(l01.y * 0.99999f > best), s2 = !(l23.x * 0.99999f > best), s3 = !(l23.y * 0.99999f > best);
+            const bool s0 = !(l01.x > thr), s1 = !(l01.y > thr), s2 = !(l23.x > thr), s3 = !(l23.y > thr);
             minlb = fminf(minlb, fminf(fminf(s0 ? FLT_MAX : l01.x, s1 ? FLT_MAX : l01.y), fminf(s2 ? FLT_MAX : l23.x, s3 ? FLT_MAX : l23.y)));   // skipped right here
-            if (!(m * 0.99999f > best)) {
+            if (!(m > thr)) {
                 const int c = (l01.x == m) ? 0 : (l01.y == m) ? 1 : (l23.x == m) ? 2 : 3;
                 const unsigned int pend = ((s0 ? 1u : 0u) | (s1 ? 2u : 0u) | (s2 ? 4u : 0u) | (s3 ? 8u : 0u)) & ~(1u << c);
                 if (pend) {
@@ -470,12 +474,13 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const f2* p2, 
                 }
                 st.idx = (st.idx << 2) | c; st.L++;
             } else st.alive = false;                      // all four children pruned
-            quad_pop(st, lbq, tid, nthreads, best, minlb);
+            quad_pop(st, lbq, tid, nthreads, thr, minlb);
         }
         if (st.alive) {
             leaf_eval<DIM>(bv.leaves + st.idx, st.idx, p2, best, bi, bpos, best2);
+            thr = fminf(best * 1.00002f, FLT_MAX);
             st.alive = false;
-            quad_pop(st, lbq, tid, nthreads, best, minlb);
+            quad_pop(st, lbq, tid, nthreads, thr, minlb);
         }
     }
 }
