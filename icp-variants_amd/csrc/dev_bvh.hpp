@@ -5,14 +5,16 @@
 // kd-tree over xyz or over the 6-D xyz+rgb/255 features) rebuilt on the device as a balanced kd-tree in implicit heap
 // layout, queried with the SAME fp32 distance and the same lexicographic (d2, lowest index) argmin as k_knn_brute<DIM> --
 // bit-identical results, O(log M) nodes per query instead of M distance evaluations.  DIM = 3 or 6.
-//   build : level by level, every node's points are sorted along the widest axis of the node's bounding box
-//           (one rocPRIM sort per level over keys (node id << 32 | ordered coordinate bits)); the implicit node k
-//           covers a fixed, leaf-aligned slice of the array, so the count-balanced median split is simply
-//           "first half / second half".  Leaves hold BVH_LEAF points SoA + original indices; node records hold BOTH
-//           child boxes, pair-interleaved for packed-f32 math, and are filled bottom-up.
-//   query : one lane = one query, depth-first "near child first".  A node is skipped only if its box lower bound
+//   build : level by level, every node's points are sorted along the widest axis of the node's bounding box; the implicit
+//           node k covers a fixed, leaf-aligned slice of the array, so the count-balanced median split is simply "first
+//           half / second half".  Slices > 2048 points: one rocPRIM sort per level over keys (node id << 32 | ordered
+//           coordinate bits); below that, all remaining levels in one LDS kernel (k_bvh_block_levels).  Leaves hold
+//           BVH_LEAF points SoA + original indices; binary node records hold BOTH child boxes, pair-interleaved for
+//           packed-f32 math, filled bottom-up; the 1-NN walk uses 4-wide nodes derived from them (two levels collapsed)
+//           and 32-byte target records in leaf order.
+//   query : one lane = one query, depth-first "nearest child first".  A node is skipped only if its box lower bound
 //           exceeds the running best; the bound uses the same operation sequence as the point distance, so by
-//           monotonicity of IEEE rounding fl(d2(point)) >= fl(lb) for every point in the box (a 1e-5 relative margin is
+//           monotonicity of IEEE rounding fl(d2(point)) >= fl(lb) for every point in the box (a 2e-5 relative margin is
 //           kept on top).  Equal distances resolve to the lowest original index, exactly like the strict-< scan
 //           (NearestNeighbor.h:87).
 #ifndef ICP_PREFETCH_PATH
@@ -28,8 +30,8 @@ typedef BvhNodeT<3> BvhNode;
 typedef BvhLeafT<3> BvhLeaf;
 
 // 4-wide node of the same tree with two binary levels collapsed: the boxes of the four grandchildren, SoA per axis (two
-// packed-f32 pairs each).  96 B / 192 B.  Half the dependent loads per query of the binary walk -- the search is bound by
-// the latency of that chain, not by bytes or flops.  128 B / 256 B.
+// packed-f32 pairs each).  Half the dependent loads per query of the binary walk -- the search is bound by the latency of
+// that chain, not by bytes or flops.
 template <int DIM> struct BvhQuadT { float lo[DIM][4]; float hi[DIM][4]; float pad[DIM == 3 ? 8 : 16]; };   // padded to one / two 128-byte lines
 
 // Everything the loop needs about a matched target point in ONE 32-byte record, stored in kd (leaf) order -- position
@@ -493,13 +495,14 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nb) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
 }
 
-// Every lane walks the tree on its own for its own query.  Measured on MI355X (370k x 370k, DIM 3): ~26 node records and
-// ~3 leaves per query, ~50 % of the wave time waiting on dependent loads, ~33 % of the lanes active on average (traversal
-// lengths differ per lane).  What moved it: Morton-sorted queries + XCD-contiguous slices (L2 hit 59 % -> 89 %), the
-// 2-byte-per-level stack (occupancy), temporal seeding, and -- once ICP has converged -- the verify-and-skip test below,
-// which retires whole waves without a traversal.  Tried and rejected (slower, see git history): wave-packet
-// traversal with scalar node loads (the union of 64 lanes' subtrees is 3x larger), persistent lanes with wave-level
-// refill (fewer waves in flight), a second cooperative pass for queries over a step budget.
+// Every lane walks the tree on its own for its own query.  Measured on MI355X (370k x 370k, DIM 3): 12.5 4-wide nodes and
+// 3.1 leaves per walked query, ~40 % of the lanes active on average (walk lengths differ per lane: 15.6 steps on average,
+// ~70 for the longest), a third of the wave time waiting on dependent loads.  The kernel lasts as long as its longest walks.
+// What moved it: kd-ordered tree, Morton-sorted queries + XCD-contiguous slices, compact per-level stack in LDS, temporal
+// seeding, the verify-and-skip test below (which retires whole waves without a walk once ICP has converged), 4-wide nodes.
+// Measured and not adopted: wave-packet traversal with scalar node loads, persistent lanes with
+// wave-level refill, a second cooperative pass for over-budget queries, block-level re-packing of the walking queries, a
+// separate verify pass + packed walk pass (kept behind ICP_HIP_TWO_PASS=1), raised wave priority for long walkers.
 template <int DIM>
 __device__ __forceinline__ void knn_load_query(const KnnParams& kp, int k, float* p) {
     const int i = kp.sel ? kp.sel[k] : k;
