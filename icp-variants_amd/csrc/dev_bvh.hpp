@@ -17,6 +17,9 @@
 //           monotonicity of IEEE rounding fl(d2(point)) >= fl(lb) for every point in the box (a 2e-5 relative margin is
 //           kept on top).  Equal distances resolve to the lowest original index, exactly like the strict-< scan
 //           (NearestNeighbor.h:87).
+#ifndef ICP_COOP_MAX
+#define ICP_COOP_MAX 3          // a wave with at most this many (seeded) queries left to search does them cooperatively; 0 = never
+#endif
 #ifndef ICP_PREFETCH_PATH
 #define ICP_PREFETCH_PATH 1
 #endif
@@ -535,6 +538,85 @@ __device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, cons
     if (kp.qstate) { float4 s; s.x = p[0]; s.y = p[1]; s.z = p[2]; s.w = lb_others; kp.qstate[k] = s; }
     if (kp.nn_raw) kp.nn_raw[k] = bpos;
     if (kp.d2_out) kp.d2_out[k] = best;
+}
+
+// ---- wave-cooperative search of ONE query -----------------------------------------------------------------------------
+// Once ICP has converged almost every query is verified without a walk; the few that are not (and the far-away queries with
+// long walks in general) then decide how long the kernel runs: a lone lane pays ~0.3 us per dependent step for 30-50 steps
+// while 63 lanes idle.  Here the whole wave searches for that one query: level-synchronous over the 4-wide tree, one frontier
+// node per lane (all four child boxes against the SEED bound, survivors compacted with ballots into the next frontier), then
+// one leaf per lane, then a lexicographic wave minimum -- about Lq + 2 dependent steps instead of the length of the walk.
+// Same prune rule and same leaf evaluation as the per-lane walk, hence the same exact (d2, lowest index) result; the bound
+// on all other targets comes out the same way (smallest skipped box bound / evaluated non-winner).  The frontier lives in the
+// wave's own (idle) stack slots: .x / .y of the uint2 slots are the two buffers, Lq * 64 entries each.
+// Returns false (outputs untouched) when a frontier would overflow -> the caller falls back to the per-lane walk.
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+template <int DIM, int NT>
+__device__ __forceinline__ bool coop_search(const BvhViewT<DIM>& bv, const float* q /* wave-uniform */, float& best, int& bi, int& bpos, float& lb_others,
+                                            uint2* __restrict__ lbq, int tid) {
+    const int lane = tid & 63, wbase = tid & ~63;          // this wave's slots: lbq[row * NT + wbase + col]
+    const int Lq = bv.Lq, cap = Lq * WAVE;
+    f2 p2[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { p2[k].x = q[k]; p2[k].y = q[k]; }
+    const float thr = fminf(best * 1.00002f, FLT_MAX);
+    float minlb = FLT_MAX;
+    unsigned int* slot = (unsigned int*)lbq;               // entry e of buffer b: slot[2 * ((e >> 6) * NT + wbase + (e & 63)) + b]
+    int n = 1, cur = 0;
+    if (lane == 0) slot[2 * (wbase) + 0] = 0u;
+    for (int L = 0; L < Lq; L++) {
+        int nn = 0;                                        // wave-uniform size of the next frontier
+        for (int base = 0; base < n; base += WAVE) {
+            const int e = base + lane;
+            const bool act = e < n;
+            const unsigned int node = act ? slot[2 * ((e >> 6) * NT + wbase + (e & 63)) + cur] : 0u;
+            f2 l01, l23;
+            quad_lb<DIM>(bv.qnodes + ((0x55555555u & ((1u << (2 * L)) - 1u)) + node), p2, l01, l23);
+            const bool s0 = act && !(l01.x > thr), s1 = act && !(l01.y > thr), s2 = act && !(l23.x > thr), s3 = act && !(l23.y > thr);
+            if (act) minlb = fminf(minlb, fminf(fminf(s0 ? FLT_MAX : l01.x, s1 ? FLT_MAX : l01.y), fminf(s2 ? FLT_MAX : l23.x, s3 ? FLT_MAX : l23.y)));
+            const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1), m2 = __ballot(s2), m3 = __ballot(s3);
+            const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
+            if (nn + c0 + c1 + c2 + c3 > cap) return false;                                   // uniform
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int o0 = nn + __popcll(m0 & lt), o1 = nn + c0 + __popcll(m1 & lt), o2 = nn + c0 + c1 + __popcll(m2 & lt), o3 = nn + c0 + c1 + c2 + __popcll(m3 & lt);
+            const unsigned int ch = node << 2;
+            if (s0) slot[2 * ((o0 >> 6) * NT + wbase + (o0 & 63)) + (cur ^ 1)] = ch;
+            if (s1) slot[2 * ((o1 >> 6) * NT + wbase + (o1 & 63)) + (cur ^ 1)] = ch | 1u;
+            if (s2) slot[2 * ((o2 >> 6) * NT + wbase + (o2 & 63)) + (cur ^ 1)] = ch | 2u;
+            if (s3) slot[2 * ((o3 >> 6) * NT + wbase + (o3 & 63)) + (cur ^ 1)] = ch | 3u;
+            nn += c0 + c1 + c2 + c3;
+        }
+        n = nn; cur ^= 1;
+        if (n == 0) break;
+    }
+    // leaves: one per lane and round; every lane starts from the seed
+    float b = best, b2 = FLT_MAX; int i = bi, ps = bpos;
+    for (int base = 0; base < n; base += WAVE) {
+        const int e = base + lane;
+        if (e < n) {
+            const int leaf = (int)slot[2 * ((e >> 6) * NT + wbase + (e & 63)) + cur];
+            leaf_eval<DIM>(bv.leaves + leaf, leaf, p2, b, i, ps, b2);
+        }
+    }
+    const float wb = wave_min_f32(b);
+    const int wi = wave_min_i32(b == wb ? i : 0x7FFFFFFF);
+    const bool mine = (b == wb) && (i == wi);             // lanes holding the winner (several if it is the seed)
+    const int wl = __ffsll((long long)__ballot(mine)) - 1;
+    const int wps = __shfl(ps, wl, WAVE);
+    const float others = wave_min_f32(mine ? b2 : fminf(b, b2));      // a lane whose local winner lost: that point is an "other" too
+    minlb = wave_min_f32(minlb);
+    best = wb; bi = wi; bpos = wps;
+    lb_others = sqrtf(fminf(others, minlb)) * 0.999999f;
+    return true;
 }
 
 // The tree walk proper for query p, starting from the seed (best, bi, bpos); returns the lower bound on the distance to every

@@ -281,46 +281,70 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
     const int k = (t < kp.n) ? (qorder ? qorder[t] : t) : -1;      // (the work-list second pass never runs fused)
     bool valid = false;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, wt = 0.f;
+    float p[DIM];
+#pragma unroll
+    for (int q = 0; q < DIM; q++) p[q] = 0.f;
+    float rn0 = 0.f, rn1 = 0.f, rn2 = 0.f;
+    float best = FLT_MAX, lb_others = 0.f; int bi = -1, bpos = -1, q0 = -1;
+    float4 ra, rb; ra.x = 0.f; ra.y = 0.f; ra.z = 0.f; ra.w = 0.f; rb = ra;
+    bool need_walk = false;
     if (k >= 0) {
         // ---- front end.  Everything that depends only on the query index is requested in ONE batch (point, normal, previous
         // neighbour, search state), then the neighbour's record: two memory round trips before the verify test instead of
         // one per array -- in the late iterations, where almost no query walks, those round trips ARE the kernel.
         const int i = kp.sel ? kp.sel[k] : k;
-        float p[DIM];
         const float r0 = kp.sx[i], r1 = kp.sy[i], r2 = kp.sz[i];
         if (DIM == 6) { p[3 % DIM] = kp.scr[i]; p[4 % DIM] = kp.scg[i]; p[5 % DIM] = kp.scb[i]; }
-        const float rn0 = pp.snx[i], rn1 = pp.sny[i], rn2 = pp.snz[i];
+        rn0 = pp.snx[i]; rn1 = pp.sny[i]; rn2 = pp.snz[i];
         const bool seeded = kp.use_prev != 0, inc = kp.incremental && seeded;
-        const int q0 = seeded ? kp.nn_raw[k] : -1;
+        q0 = seeded ? kp.nn_raw[k] : -1;
         float4 st; st.x = 0.f; st.y = 0.f; st.z = 0.f; st.w = 0.f;
         if (inc) st = kp.qstate[k];
         xform_point(kp.ps->pose, r0, r1, r2, p[0], p[1], p[2]);
-        float best = FLT_MAX, lb_others = 0.f; int bi = -1, bpos = -1;
-        float4 ra, rb; ra.x = 0.f; ra.y = 0.f; ra.z = 0.f; ra.w = 0.f; rb = ra;
         if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
-            bool verified = false;
+            need_walk = true;
             if (q0 >= 0) {                                 // seed_from_previous + knn_try_verify, on the batched loads
-                float t[DIM]; int j0;
-                if (DIM == 3) { ra = *(const float4*)(bv.recs + q0); rb = *((const float4*)(bv.recs + q0) + 1); t[0] = ra.x; t[1] = ra.y; t[2] = ra.z; j0 = __float_as_int(ra.w); }
+                float tq[DIM]; int j0;
+                if (DIM == 3) { ra = *(const float4*)(bv.recs + q0); rb = *((const float4*)(bv.recs + q0) + 1); tq[0] = ra.x; tq[1] = ra.y; tq[2] = ra.z; j0 = __float_as_int(ra.w); }
                 else {
                     const BvhLeafT<DIM>* lf = bv.leaves + (q0 >> 3);
 #pragma unroll
-                    for (int q = 0; q < DIM; q++) t[q] = lf->c[q][q0 & 7];
+                    for (int q = 0; q < DIM; q++) tq[q] = lf->c[q][q0 & 7];
                     j0 = lf->idx[q0 & 7];
                 }
                 float d = 0.f;
 #pragma unroll
-                for (int q = 0; q < DIM; q++) { const float e = p[q] - t[q]; d = (q == 0) ? e * e : d + e * e; }
+                for (int q = 0; q < DIM; q++) { const float e = p[q] - tq[q]; d = (q == 0) ? e * e : d + e * e; }
                 if (d < best) { best = d; bi = j0; bpos = q0; }
                 if (inc && bi >= 0) {
                     const float ex = p[0] - st.x, ey = p[1] - st.y, ez = p[2] - st.z;
                     const float delta = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.000001f + 1e-30f;
                     const float lbn = (st.w - delta) * 0.999999f;
-                    if (sqrtf(best) * 1.000001f < lbn) { lb_others = lbn; verified = true; }
+                    if (sqrtf(best) * 1.000001f < lbn) { lb_others = lbn; need_walk = false; }
                 }
             }
-            if (!verified) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, bvh_lbq, tid);
         }
+    }
+    // ---- the walks.  A wave left with only a few seeded queries to search does them cooperatively, one after the other
+    // (coop_search); otherwise every lane walks on its own.
+    {
+        unsigned long long wm = __ballot(need_walk);
+        const unsigned long long cm = __ballot(need_walk && bpos >= 0);
+        if (ICP_COOP_MAX > 0 && wm != 0ull && wm == cm && __popcll(wm) <= ICP_COOP_MAX && bv.Lq > 0) {
+            const int lane = tid & 63;
+            while (wm) {
+                const int src = __ffsll((long long)wm) - 1; wm &= wm - 1ull;
+                float q[DIM];
+#pragma unroll
+                for (int a = 0; a < DIM; a++) q[a] = __shfl(p[a], src, WAVE);
+                float b = __shfl(best, src, WAVE), lbo = 0.f; int ci = __shfl(bi, src, WAVE), cps = __shfl(bpos, src, WAVE);
+                const bool done = coop_search<DIM, BVH_THREADS>(bv, q, b, ci, cps, lbo, bvh_lbq, tid);      // wave-uniform
+                if (done && lane == src) { best = b; bi = ci; bpos = cps; lb_others = lbo; need_walk = false; }
+            }
+        }
+    }
+    if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, bvh_lbq, tid);
+    if (k >= 0) {
         knn_store_state<DIM>(kp, k, p, best, bpos, lb_others);
         icp_match_t m;
         if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
