@@ -18,7 +18,7 @@
 //           kept on top).  Equal distances resolve to the lowest original index, exactly like the strict-< scan
 //           (NearestNeighbor.h:87).
 #ifndef ICP_COOP_MAX
-#define ICP_COOP_MAX 3          // a wave with at most this many (seeded) queries left to search does them cooperatively; 0 = never
+#define ICP_COOP_MAX 2          // a wave with at most this many (seeded) queries left to search does them cooperatively; 0 = never
 #endif
 #ifndef ICP_PREFETCH_PATH
 #define ICP_PREFETCH_PATH 1
