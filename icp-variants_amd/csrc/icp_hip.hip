@@ -66,6 +66,7 @@ struct icp_ctx {
     bool owns_stream = false;
     int stage_timing = 1;                // icp_set_stage_timing: 0 none, 1 every iteration, N > 1 every Nth iteration (scaled)
     unsigned timing_phase = 0;           // rotates the sampled iterations from run to run
+    void* pinned = nullptr; size_t pinned_cap = 0;   // page-locked host staging: pose upload, stats + pose download (truly asynchronous copies)
     bool block_levels = true;            // BVH build: levels with slices <= 2048 points in one LDS kernel (ICP_HIP_BLOCK_LEVELS=0: global sorts)
     bool trace = false;                  // ICP_HIP_TRACE=1: per-iteration stage times on stderr
     bool two_pass = false;               // incremental k-NN as verify pass + packed tree-walk pass (ICP_HIP_TWO_PASS=1; measured slower: walk latency is exposed)
@@ -98,6 +99,14 @@ int ensure(icp_ctx* c, DevBuf& b, size_t bytes) {
     size_t want = bytes < 256 ? 256 : bytes;
     HIPCK(c, hipMalloc(&b.p, want));
     b.cap = want;
+    return ICP_OK;
+}
+int ensure_pinned(icp_ctx* c, size_t bytes) {
+    if (bytes <= c->pinned_cap && c->pinned) return ICP_OK;
+    if (c->pinned) { HIPCK(c, hipHostFree(c->pinned)); c->pinned = nullptr; c->pinned_cap = 0; }
+    const size_t want = bytes < 4096 ? 4096 : bytes;
+    HIPCK(c, hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
+    c->pinned_cap = want;
     return ICP_OK;
 }
 void release(DevBuf& b) { if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; } }
@@ -162,14 +171,16 @@ int upload_cloud(icp_ctx* c, Cloud& cl, const float* xyz, const float* nrm, cons
     return ICP_OK;
 }
 
+// Upload the pose state.  Staged through the context's page-locked buffer: no synchronisation here -- every entry point
+// that uses the pose synchronises the stream before it returns, so the staging area is free again by the next call.
 int write_pose(icp_ctx* c, const float pose[16]) {
-    PoseState h; memset(&h, 0, sizeof(h));
-    memcpy(h.pose, pose, 64);
-    normal_matrix_from_pose(h.pose, h.nmat);
     int rc;
+    if ((rc = ensure_pinned(c, sizeof(PoseState)))) return rc;
+    PoseState* h = (PoseState*)c->pinned; memset(h, 0, sizeof(*h));
+    memcpy(h->pose, pose, 64);
+    normal_matrix_from_pose(h->pose, h->nmat);
     if ((rc = ensure(c, c->ps, sizeof(PoseState)))) return rc;
-    HIPCK(c, hipMemcpyAsync(c->ps.p, &h, sizeof(h), hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));      // h is a stack object
+    HIPCK(c, hipMemcpyAsync(c->ps.p, h, sizeof(*h), hipMemcpyHostToDevice, c->stream));
     return ICP_OK;
 }
 
@@ -559,6 +570,7 @@ int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out) {
     c->cos_reject = compute_cos_reject();
     float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     int rc = write_pose(c, ident);
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = ICP_ERR_HIP;
     if (rc) { icp_ctx_destroy(c); return rc; }
     *out = c;
     return ICP_OK;
@@ -577,6 +589,7 @@ int icp_ctx_destroy(icp_ctx* c) {
     for (auto& kv : c->levels) release(kv.second);
     release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->work_items); release(c->work_counts); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -732,9 +745,12 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     const int iters = (int)factors.size();
     if (n_run) *n_run = 0;
     if (iters == 0) return ICP_OK;
+    // page-locked staging for the whole run up front: [pose state up | per-iteration records down | pose state down]
+    const size_t pin_stats = 256, pin_pose = pin_stats + (((size_t)iters * sizeof(icp_iter_stats) + 255) & ~(size_t)255);
+    if ((rc = ensure_pinned(c, pin_pose + 256))) return rc;
     if ((rc = write_pose(c, pose_inout))) return rc;
     if ((rc = ensure(c, c->stats, (size_t)iters * sizeof(icp_iter_stats)))) return rc;
-    HIPCK(c, hipMemsetAsync(c->stats.p, 0, (size_t)iters * sizeof(icp_iter_stats), c->stream));
+    // (every record of an iteration with work is written in full by k_reduce_solve; empty iterations are filled in on the host)
     if ((rc = ensure_events(c, (size_t)iters * 4 + 2))) return rc;
     // resolve selections up front (uploads) so the loop itself is launch-only
     std::vector<const int*> sels(iters, nullptr); std::vector<int> ns(iters, c->src.n);
@@ -784,7 +800,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     c->timing_phase++;
     auto E = [&](int i, int k) { return c->events[(size_t)2 + 4 * i + k]; };
     auto start_event = [&](int i) { return (i > 0 && sampled[i - 1]) ? E(i - 1, 3) : E(i, 0); };
-    if (p.knn_backend == ICP_KNN_LBVH && p.matching == ICP_MATCH_KNN && p.knn_incremental) {     // work-list counters, one per iteration
+    if (c->two_pass && p.knn_backend == ICP_KNN_LBVH && p.matching == ICP_MATCH_KNN && p.knn_incremental) {     // work-list counters, one per iteration
         if ((rc = ensure(c, c->work_counts, (size_t)iters * 4))) return rc;
         HIPCK(c, hipMemsetAsync(c->work_counts.p, 0, (size_t)iters * 4, c->stream));
     }
@@ -817,14 +833,14 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     }
     HIPCK(c, hipEventRecord(c->events[1], c->stream));
     std::vector<icp_iter_stats> hs((size_t)iters);
-    PoseState hp;
-    HIPCK(c, hipMemcpyAsync(hs.data(), c->stats.p, (size_t)iters * sizeof(icp_iter_stats), hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipMemcpyAsync(&hp, c->ps.p, sizeof(hp), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_stats, c->stats.p, (size_t)iters * sizeof(icp_iter_stats), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_pose, c->ps.p, sizeof(PoseState), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    memcpy(pose_inout, hp.pose, 64);
+    memcpy(hs.data(), (char*)c->pinned + pin_stats, (size_t)iters * sizeof(icp_iter_stats));
+    memcpy(pose_inout, ((const PoseState*)((char*)c->pinned + pin_pose))->pose, 64);
     int status = ICP_OK;
     for (int i = 0; i < iters; i++) {
-        if (ns[i] <= 0) { hs[i].n_src = 0; hs[i].status = ICP_ERR_NO_CORRESPONDENCES; memcpy(hs[i].pose, i ? hs[i - 1].pose : pose_inout, 64); hs[i].rmse = -1.f; hs[i].benchmark_error = -1.f; }
+        if (ns[i] <= 0) { hs[i].n_src = 0; hs[i].n_valid = 0; hs[i].status = ICP_ERR_NO_CORRESPONDENCES; memcpy(hs[i].pose, i ? hs[i - 1].pose : pose_inout, 64); hs[i].rmse = -1.f; hs[i].benchmark_error = -1.f; }
         if (!rmse) hs[i].rmse = -1.f;
         if (!fontana) hs[i].benchmark_error = -1.f;
         if (hs[i].status != ICP_OK && status == ICP_OK) status = hs[i].status;
