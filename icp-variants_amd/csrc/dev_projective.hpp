@@ -32,15 +32,26 @@ __global__ __launch_bounds__(256) void k_projective(const ProjParams pp) {
             const int ve = (int)(v1 < (long long)pp.height - 1 ? v1 : (long long)pp.height - 1);
             const int ue = (int)(u1 < (long long)pp.width - 1 ? u1 : (long long)pp.width - 1);
             if (v0 < pp.height && u0 < pp.width) {
+                // Two window columns per step (packed f32, 8-byte loads), row-major order and strict < kept (:399).  A target
+                // hole (x == MINF, :392) needs no test: px - (-inf) = +inf makes its distance +inf (or NaN), never < best.
+                const f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz};
                 for (int v = (int)v0; v <= ve; v++) {
                     const int row = v * pp.width;
-                    for (int u = (int)u0; u <= ue; u++) {
+                    int u = (int)u0;
+                    for (; u + 1 <= ue; u += 2) {
                         const int j = row + u;
-                        const float qx = pp.tx[j];
-                        if (qx == -INFINITY) continue;           // :392
-                        const float dx = px - qx, dy = py - pp.ty[j], dz = pz - pp.tz[j];
-                        const float d = dx * dx + (dy * dy + dz * dz);     // :396 Eigen squaredNorm tree
-                        if (d < best) { best = d; bi = j; }      // :399
+                        f2 qx, qy, qz;
+                        __builtin_memcpy(&qx, pp.tx + j, 8); __builtin_memcpy(&qy, pp.ty + j, 8); __builtin_memcpy(&qz, pp.tz + j, 8);
+                        const f2 dx = px2 - qx, dy = py2 - qy, dz = pz2 - qz;
+                        const f2 d = dx * dx + (dy * dy + dz * dz);        // :396 Eigen squaredNorm tree
+                        if (d.x < best) { best = d.x; bi = j; }
+                        if (d.y < best) { best = d.y; bi = j + 1; }
+                    }
+                    if (u <= ue) {
+                        const int j = row + u;
+                        const float dx = px - pp.tx[j], dy = py - pp.ty[j], dz = pz - pp.tz[j];
+                        const float d = dx * dx + (dy * dy + dz * dz);
+                        if (d < best) { best = d; bi = j; }
                     }
                 }
             }
