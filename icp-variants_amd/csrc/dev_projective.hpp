@@ -38,6 +38,18 @@ __global__ __launch_bounds__(256) void k_projective(const ProjParams pp) {
                 for (int v = (int)v0; v <= ve; v++) {
                     const int row = v * pp.width;
                     int u = (int)u0;
+                    for (; u + 3 <= ue; u += 4) {                         // four columns: 16-byte loads
+                        const int j = row + u;
+                        f2 qx[2], qy[2], qz[2];
+                        __builtin_memcpy(qx, pp.tx + j, 16); __builtin_memcpy(qy, pp.ty + j, 16); __builtin_memcpy(qz, pp.tz + j, 16);
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const f2 dx = px2 - qx[h], dy = py2 - qy[h], dz = pz2 - qz[h];
+                            const f2 d = dx * dx + (dy * dy + dz * dz);
+                            if (d.x < best) { best = d.x; bi = j + 2 * h; }
+                            if (d.y < best) { best = d.y; bi = j + 2 * h + 1; }
+                        }
+                    }
                     for (; u + 1 <= ue; u += 2) {
                         const int j = row + u;
                         f2 qx, qy, qz;
