@@ -119,9 +119,10 @@ __device__ inline void solve_normal_svd(const double* sums /* 21 + 6 */, double*
 }
 
 // FullPivLU::solve with its rank rule in fp64 (ICPOptimizer.h:866-868).
-__device__ inline void solve_fullpiv_lu6(double* M, double* rhs, double* x) {
+// M, rhs, x, colp and y are caller-provided workspaces (LDS in k_reduce_solve: dynamically indexed local arrays would live in
+// scratch memory, two orders of magnitude slower per access for this single-thread code).
+__device__ inline void solve_fullpiv_lu6(double* M, double* rhs, double* x, int* colp, double* y) {
     const int n = 6;
-    int colp[6];
     for (int i = 0; i < n; i++) colp[i] = i;
     double maxpiv = 0.0; int rank = n;
     for (int k = 0; k < n; k++) {
@@ -140,7 +141,7 @@ __device__ inline void solve_fullpiv_lu6(double* M, double* rhs, double* x) {
     const double thr = 1.1920928955078125e-07 * 6.0;
     int r = 0;
     for (int k = 0; k < rank; k++) { if (fabs(M[k * n + k]) > maxpiv * thr) r++; else break; }
-    double y[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < n; k++) y[k] = 0.0;
     for (int k = r - 1; k >= 0; k--) { double s = rhs[k]; for (int j = k + 1; j < r; j++) s -= M[k * n + j] * y[j]; y[k] = s / M[k * n + k]; }
     for (int k = 0; k < n; k++) x[colp[k]] = (k < r) ? y[k] : 0.0;
 }
@@ -395,13 +396,14 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
         set_pose_f32(dT, R, t);
     } else {
         // symmetric: M = A^T A + lambda^2 I, FullPivLU (ICPOptimizer.h:858-868)
-        double M[36], g[6], x[6];
+        __shared__ double M[36], g[6], x[6], ywork[6];
+        __shared__ int colp[6];
         int q = 0;
         for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { M[a * 6 + c] = tot[SUM_M + q]; M[c * 6 + a] = tot[SUM_M + q]; q++; }
         for (int a = 0; a < 6; a++) g[a] = tot[SUM_M + 21 + a];
         const float lambda = 0.0001f; const float l2 = lambda * lambda;
         for (int a = 0; a < 6; a++) M[a * 6 + a] += (double)l2;
-        solve_fullpiv_lu6(M, g, x);
+        solve_fullpiv_lu6(M, g, x, colp, ywork);
         const float at[3] = {(float)x[0], (float)x[1], (float)x[2]}, tt[3] = {(float)x[3], (float)x[4], (float)x[5]};
         const float tan_theta = sqrtf(at[0] * at[0] + (at[1] * at[1] + at[2] * at[2]));     // :878
         const float ax[3] = {at[0] / tan_theta, at[1] / tan_theta, at[2] / tan_theta};      // :879

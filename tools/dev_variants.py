@@ -8,7 +8,7 @@ from icp_amd import binding, synth
 binding.LIB_PATH = os.path.join(binding.PKG_ROOT, "lib", sys.argv[1])
 p = synth.eth_like_pair(0)
 c = binding.Context(0)
-c.params.max_distance = 10.0; c.params.metric = 1; c.params.n_iterations = 50; c.params.knn_backend = 1; c.params.rejection = 1; c.push_params()
+c.params.max_distance = 10.0; c.params.metric = int(os.environ.get("ICP_DEV_METRIC", "1")); c.params.n_iterations = 50; c.params.knn_backend = 1; c.params.rejection = 1; c.push_params()
 c.set_target(p["tgt_pts"], p["tgt_nrm"]); c.set_source(p["src_pts"], p["src_nrm"])
 for rep in range(3):
     pose, recs, rc = c.run(np.eye(4))
