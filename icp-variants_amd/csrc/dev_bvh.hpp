@@ -17,6 +17,9 @@
 //           monotonicity of IEEE rounding fl(d2(point)) >= fl(lb) for every point in the box (a 2e-5 relative margin is
 //           kept on top).  Equal distances resolve to the lowest original index, exactly like the strict-< scan
 //           (NearestNeighbor.h:87).
+#ifndef ICP_SEED_DESCENT
+#define ICP_SEED_DESCENT 1
+#endif
 #ifndef ICP_COOP_MAX
 #define ICP_COOP_MAX 2          // a wave with at most this many (seeded) queries left to search does them cooperatively; 0 = never
 #endif
@@ -628,6 +631,21 @@ __device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* 
     for (int q = 0; q < DIM; q++) { p2[q].x = p[q]; p2[q].y = p[q]; }
     float best2 = FLT_MAX, minlb = FLT_MAX;
     unsigned int touched = 0u;
+    if (ICP_SEED_DESCENT && bpos < 0 && bv.Lq > 0) {
+        // No candidate yet (first iteration): one greedy root-to-leaf descent -- nearest child at every level, nothing parked --
+        // yields a real candidate first.  The proper walk below then prunes from the root on; without it every level parks
+        // three siblings that are popped and discarded later, which costs more instructions than these Lq extra node visits.
+        int idx = 0;
+        for (int L = 0; L < bv.Lq; L++) {
+            f2 l01, l23;
+            quad_lb<DIM>(bv.qnodes + ((0x55555555u & ((1u << (2 * L)) - 1u)) + (unsigned int)idx), p2, l01, l23);
+            const float m = fminf(fminf(l01.x, l01.y), fminf(l23.x, l23.y));
+            const int c = (l01.x == m) ? 0 : (l01.y == m) ? 1 : (l23.x == m) ? 2 : 3;
+            idx = (idx << 2) | c;
+        }
+        float unused = FLT_MAX;
+        leaf_eval<DIM>(bv.leaves + idx, idx, p2, best, bi, bpos, unused);      // (the walk re-evaluates this leaf: the bound bookkeeping stays in one place)
+    }
     if (ICP_PREFETCH_PATH && bpos >= 0) touched = quad_prefetch_path<DIM>(bv, bpos >> 3);
     QuadState st; st.L = 0; st.idx = 0; st.pending = 0ull; st.alive = true;
     quad_run<DIM>(bv, p2, st, best, bi, bpos, best2, minlb, lbq, tid, NT);
