@@ -32,6 +32,9 @@ __device__ inline void jacobi_eig_sym(double* A /* n x n, destroyed */, double* 
                     for (int k = 0; k < n; k++) { const double apk = A[p * n + k], aqk = A[q * n + k]; A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk; }
 #pragma unroll
                     for (int k = 0; k < n; k++) { const double vkp = V[k * n + p], vkq = V[k * n + q]; V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq; }
+                    // the rotation annihilates a_pq by construction; writing the exact zero (instead of the ~1e-16 |A| the formulas
+                    // leave) lets the sweep loop see convergence -- otherwise all 50 sweeps run (57 us for a 3x3 on one lane)
+                    A[p * n + q] = 0.0; A[q * n + p] = 0.0;
                 }
             }
         }
