@@ -1,4 +1,4 @@
-// dev_bvh.hpp -- exact kd-ordered BVH: build kernels, 4-wide nodes, walk, k_knn_bvh / k_knn_verify.
+// dev_bvh.hpp -- exact kd-ordered BVH: build kernels, 4-wide nodes, walk, cooperative search, k_knn_bvh.
 // Part of icp_device.hpp (included from there, inside namespace icpdev); see that file for the build contract.
 // ------------------------------------------------------------------------------------------------
 // Exact kd-ordered BVH 1-NN: the index the reference builds once per pair (NearestNeighbor.h:122-141 / :209-232, a FLANN
@@ -508,7 +508,7 @@ __device__ __forceinline__ int xcd_contiguous_block(int b, int nb) {
 // seeding, the verify-and-skip test below (which retires whole waves without a walk once ICP has converged), 4-wide nodes.
 // Measured and not adopted: wave-packet traversal with scalar node loads, persistent lanes with
 // wave-level refill, a second cooperative pass for over-budget queries, block-level re-packing of the walking queries, a
-// separate verify pass + packed walk pass (kept behind ICP_HIP_TWO_PASS=1), raised wave priority for long walkers.
+// separate verify pass + packed walk pass, raised wave priority for long walkers.
 template <int DIM>
 __device__ __forceinline__ void knn_load_query(const KnnParams& kp, int k, float* p) {
     const int i = kp.sel ? kp.sel[k] : k;
@@ -666,16 +666,8 @@ __device__ __forceinline__ void knn_bvh_query(const KnnParams& kp, const BvhView
     knn_store_state<DIM>(kp, k, p, best, bpos, lb_others);
 }
 
-// Which query does this lane serve?  Either position t of the (Morton-sorted) query order, or -- second pass of the
-// incremental search -- entry t of the work list, whose length is only known on the device: the launch covers the worst case
-// and blocks past the end retire at once; the XCD-contiguous slices are cut over the blocks actually in use.
+// Which query does this lane serve?  Position t of the (Morton-sorted) query order, in XCD-contiguous slices.
 __device__ __forceinline__ int knn_bvh_lane_query(const KnnParams& kp, const int* __restrict__ qorder, int tid) {
-    if (kp.work_items) {
-        const int n = *kp.work_n, nb = (n + BVH_THREADS - 1) / BVH_THREADS;
-        if ((int)blockIdx.x >= nb) return -1;
-        const int t = xcd_contiguous_block(blockIdx.x, nb) * BVH_THREADS + tid;
-        return t < n ? kp.work_items[t] : -1;
-    }
     const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS + tid;
     if (t >= kp.n) return -1;
     return qorder ? qorder[t] : t;                        // spatially sorted queries: neighbouring lanes walk similar paths
@@ -694,36 +686,3 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, con
     kp.out[k] = m;
 }
 
-// First pass of the incremental search: a streaming kernel that re-evaluates every query against its previous neighbour.
-// Verified queries are finished here; the others are appended to the work list for the tree walk (one wave-aggregated
-// atomic per wave; the list order varies from run to run, the per-query results do not depend on it).  Packing the
-// survivors densely matters: left in place they would keep almost every wave walking the tree at a few lanes' utilisation.
-constexpr int VERIFY_THREADS = 256;
-template <int DIM>
-__global__ __launch_bounds__(VERIFY_THREADS) void k_knn_verify(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder) {
-    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * VERIFY_THREADS + threadIdx.x;
-    bool push = false; int k = -1;
-    if (t < kp.n) {
-        k = qorder ? qorder[t] : t;
-        float p[DIM];
-        knn_load_query<DIM>(kp, k, p);
-        float best = FLT_MAX, lb_others = 0.f; int bi = -1, bpos = -1;
-        if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
-            push = !knn_try_verify<DIM>(kp, bv, k, p, best, bi, bpos, lb_others);
-        }
-        if (!push) {
-            knn_store_state<DIM>(kp, k, p, best, bpos, lb_others);
-            icp_match_t m;
-            if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
-            kp.out[k] = m;
-        }
-    }
-    const unsigned long long mask = __ballot(push);
-    if (mask) {
-        const int lane = threadIdx.x & 63;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(kp.work_n, __popcll(mask));
-        base = __shfl(base, 0, WAVE);
-        if (push) kp.work_items[base + __popcll(mask & ((1ull << lane) - 1ull))] = k;
-    }
-}

@@ -27,7 +27,6 @@ struct KnnParams {
     int use_prev;                                            // 1: nn_raw holds the previous iteration's result for the same queries
     float4* qstate;                                          // [n] (query xyz when last searched or verified, lower bound on the distance to every OTHER target)
     int incremental;                                         // 1: verify-and-skip with qstate (needs use_prev)
-    int* work_items; int* work_n;                            // two-pass incremental search: queries that failed verification (list, count)
 };
 
 template <int DIM>

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
     constexpr int NW = BVH_THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS + tid;
-    const int k = (t < kp.n) ? (qorder ? qorder[t] : t) : -1;      // (the work-list second pass never runs fused)
+    const int k = (t < kp.n) ? (qorder ? qorder[t] : t) : -1;
     bool valid = false;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, wt = 0.f;
     float p[DIM];
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
             for (int l = 0; l < 16; l++) part += row[l];
             tot += part;
         }
-        const int lb = kp.work_items ? (int)blockIdx.x : xcd_contiguous_block(blockIdx.x, gridDim.x);             // partial slot = logical block -> fixed summation order
+        const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);             // partial slot = logical block -> fixed summation order
         pp.partials[(size_t)tid * gridDim.x + lb] = tot;
     }
 }

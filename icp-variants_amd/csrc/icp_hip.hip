@@ -69,7 +69,6 @@ struct icp_ctx {
     void* pinned = nullptr; size_t pinned_cap = 0;   // page-locked host staging: pose upload, stats + pose download (truly asynchronous copies)
     bool block_levels = true;            // BVH build: levels with slices <= 2048 points in one LDS kernel (ICP_HIP_BLOCK_LEVELS=0: global sorts)
     bool trace = false;                  // ICP_HIP_TRACE=1: per-iteration stage times on stderr
-    bool two_pass = false;               // incremental k-NN as verify pass + packed tree-walk pass (ICP_HIP_TWO_PASS=1; measured slower: walk latency is exposed)
     bool fuse_post = true;               // BVH matcher runs weight / reject / accumulate as its epilogue (ICP_HIP_FUSE_POST=0 disables)
     icp_params prm;
     Cloud tgt, src, qry;                 // qry: scratch cloud of icp_query_matches
@@ -81,7 +80,7 @@ struct icp_ctx {
     std::map<int, Level> levels;         // multires selections by decimation factor
     DevBuf sel_lists, sel_counts, sel_blocks;            // RANDOM_SAMPLING: per-iteration index lists, their sizes, scan scratch
     DevBuf qstate;                                       // incremental k-NN: per-query position + bound on the other targets
-    DevBuf ps, matches, d2, best64, nn_raw, work_items, work_counts, partials, totals, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
+    DevBuf ps, matches, d2, best64, nn_raw, partials, totals, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
     Cloud conv_src, conv_ref; int conv_n = 0;
     float cos_reject = 0.5f;
     std::vector<hipEvent_t> events;
@@ -184,7 +183,7 @@ int write_pose(icp_ctx* c, const float pose[16]) {
     return ICP_OK;
 }
 
-struct QuerySet { const Cloud* cl; const int* sel; int n; int pretransformed; bool use_colors; bool seed_prev; const int* order; int work_slot = -1; };   // cl/sel: also what the post stage reads
+struct QuerySet { const Cloud* cl; const int* sel; int n; int pretransformed; bool use_colors; bool seed_prev; const int* order; };   // cl/sel: also what the post stage reads
 
 int ensure_match_buffers(icp_ctx* c, int n) {
     int rc;
@@ -322,12 +321,7 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
     bv.qnodes = b.qnodes.as<BvhQuadT<DIM>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>();
     const int nb = (n + BVH_THREADS - 1) / BVH_THREADS;
     const size_t stack_bytes = (size_t)(b.Lq > 0 ? b.Lq : 1) * BVH_THREADS * 8;
-    if (kp.work_items) {
-        // incremental search in two passes: verify everything (streaming), then walk the tree for the densely packed rest
-        KnnParams first = kp;
-        hipLaunchKernelGGL(k_knn_verify<DIM>, dim3((n + VERIFY_THREADS - 1) / VERIFY_THREADS), dim3(VERIFY_THREADS), 0, c->stream, first, bv, order);
-        hipLaunchKernelGGL(k_knn_bvh<DIM>, dim3(nb), dim3(BVH_THREADS), stack_bytes, c->stream, kp, bv, (const int*)nullptr);
-    } else if (fuse) {
+    if (fuse) {
         if ((rc = ensure(c, c->partials, (size_t)(nb > POST_BLOCKS ? nb : POST_BLOCKS) * NSUM * 8))) return rc;
         const PostParams pp = make_post_params(c, *fuse, kp.sel, n);
         const size_t red_bytes = (size_t)(BVH_THREADS / WAVE) * 34 * 17 * 8;      // the reduction reuses the (dead) traversal stacks
@@ -373,11 +367,6 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr) {
         if (p.knn_incremental && !q.pretransformed) {
             if ((rc = ensure(c, c->qstate, (size_t)q.n * 16))) return rc;
             kp.qstate = c->qstate.as<float4>(); kp.incremental = 1;
-        }
-        kp.work_items = nullptr; kp.work_n = nullptr;
-        if (kp.incremental && kp.use_prev && q.work_slot >= 0 && c->two_pass) {
-            if ((rc = ensure(c, c->work_items, (size_t)q.n * 4))) return rc;
-            kp.work_items = c->work_items.as<int>(); kp.work_n = c->work_counts.as<int>() + q.work_slot;
         }
         const Cloud* fuse = (fused_blocks != nullptr && p.metric != ICP_METRIC_SYMMETRIC && !q.pretransformed) ? q.cl : nullptr;
         if (q.use_colors) return launch_bvh_query<6>(c, c->bvh6, target_coords6(c), kp, q.order, q.n, fuse, fused_blocks);
@@ -560,7 +549,6 @@ int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out) {
     { const char* e = getenv("ICP_HIP_FUSE_POST"); if (e && e[0] == '0') c->fuse_post = false; }
     { const char* e = getenv("ICP_HIP_BLOCK_LEVELS"); if (e && e[0] == '0') c->block_levels = false; }
     { const char* e = getenv("ICP_HIP_TRACE"); if (e && e[0] == '1') c->trace = true; }
-    { const char* e = getenv("ICP_HIP_TWO_PASS"); if (e && e[0] == '1') c->two_pass = true; }
     { const char* e = getenv("ICP_HIP_STAGE_EVENTS"); if (e && e[0] >= '0' && e[0] <= '9') c->stage_timing = atoi(e); }
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->owns_stream = false; }
     else {
@@ -587,7 +575,7 @@ int icp_ctx_destroy(icp_ctx* c) {
     for (Bvh* b : {&c->bvh6, &c->nrm_bvh}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
     release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) release(kv.second);
-    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->work_items); release(c->work_counts); release(c->sums);
+    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -800,10 +788,6 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     c->timing_phase++;
     auto E = [&](int i, int k) { return c->events[(size_t)2 + 4 * i + k]; };
     auto start_event = [&](int i) { return (i > 0 && sampled[i - 1]) ? E(i - 1, 3) : E(i, 0); };
-    if (c->two_pass && p.knn_backend == ICP_KNN_LBVH && p.matching == ICP_MATCH_KNN && p.knn_incremental) {     // work-list counters, one per iteration
-        if ((rc = ensure(c, c->work_counts, (size_t)iters * 4))) return rc;
-        HIPCK(c, hipMemsetAsync(c->work_counts.p, 0, (size_t)iters * 4, c->stream));
-    }
     HIPCK(c, hipEventRecord(c->events[0], c->stream));
     for (int i = 0; i < iters; i++) {
         icp_iter_stats* d_st = c->stats.as<icp_iter_stats>() + i;
@@ -813,7 +797,6 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
             // seed the search with the previous iteration's neighbours when it matched the same queries (same level)
             const bool seed = i > 0 && factors[i] == factors[i - 1] && ns[i - 1] > 0 && p.selection == 0;
             QuerySet q{clouds[i], sels[i], ns[i], 0, p.color_icp != 0 && p.matching == ICP_MATCH_KNN, seed, orders[i]};
-            q.work_slot = i;
             int fused = 0;
             if ((rc = launch_match(c, q, c->fuse_post ? &fused : nullptr))) return rc;
             if (ev) HIPCK(c, hipEventRecord(E(i, 1), c->stream));
@@ -864,13 +847,6 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
         t.match_ms *= f; t.weight_reject_build_ms *= f; t.solve_ms *= f;
     }
     t.sampled_iterations = n_sampled;
-    if (c->trace && c->work_counts.p && c->two_pass) {
-        std::vector<int> wc((size_t)iters);
-        HIPCK(c, hipMemcpy(wc.data(), c->work_counts.p, (size_t)iters * 4, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[icp_hip] tree walks per iteration:");
-        for (int i = 0; i < iters; i++) fprintf(stderr, " %d", wc[i]);
-        fprintf(stderr, "\n");
-    }
     float tot = 0; HIPCK(c, hipEventElapsedTime(&tot, c->events[0], c->events[1])); t.total_ms = tot;
     if (status != ICP_OK) c->err = "no valid correspondences in at least one iteration (reference would hang in ASSERT)";
     return status;
