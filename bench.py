@@ -30,9 +30,10 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: peak FP32 vector
 
 
-def cpu_baseline(pair, n_iter=2, threads=None):
+def cpu_baseline(pair, n_iter=100, threads=None):
     """Oracle (CPU restatement) timed on the host cores: exact kd-tree matcher (stand-in for the FLANN kd-tree the
-    reference instantiates, NearestNeighbor.h:122-207) + reference-shaped fp32 dense solve.  Bounded sample."""
+    reference instantiates, NearestNeighbor.h:122-207) + reference-shaped fp32 dense solve.  Bounded sample: 100 iterations
+    (two steps' worth of the workload, about 10 s of wall time on the GPU box's host cores)."""
     from oracle import oracle as orc
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = threads or max(1, min(16, ncpu))
