@@ -109,3 +109,28 @@ def test_context_reuse_across_pairs_lbvh(gpu_ctx_factory, orc, bunny, small_pair
     c.set_source(bunny["src_pts"], bunny["src_nrm"])
     again, _, _ = c.run(np.eye(4))
     assert np.array_equal(mid, again)
+
+
+def test_concurrent_contexts_on_one_device_are_independent(gpu_ctx_factory, bunny, small_pair):
+    """bench.py --pairs / --resident-pairs drive several contexts (one HIP stream and one host thread each) on the same GPU at
+    once: every context must produce exactly what it produces alone."""
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = [(bunny, 0.0003, 1), (small_pair, 0.3, 1), (bunny, 0.0003, 0), (small_pair, 0.3, 2)]
+
+    def make(job):
+        d, thr, metric = job
+        c = gpu_ctx_factory()
+        c.params.max_distance = thr; c.params.metric = metric; c.params.n_iterations = 15; c.params.knn_backend = LBVH; c.push_params()
+        c.set_target(d["tgt_pts"], d["tgt_nrm"]); c.set_source(d["src_pts"], d["src_nrm"])
+        return c
+
+    ctxs = [make(j) for j in jobs]
+    alone = [c.run(np.eye(4))[0] for c in ctxs]
+    pools = [ThreadPoolExecutor(1) for _ in ctxs]
+    for _ in range(5):
+        futs = [pl.submit(lambda cc=c: cc.run(np.eye(4))[0]) for pl, c in zip(pools, ctxs)]
+        together = [f.result() for f in futs]
+        for a, b in zip(alone, together):
+            assert np.array_equal(a, b)
+    for pl in pools:
+        pl.shutdown()
