@@ -1,5 +1,5 @@
 """Dev check at 4x the bench size (1.48 M x 1.48 M points): match indices bit-exact against the oracle's kd-tree, incremental
-run equal to the non-incremental one, timings.  usage: python tools/dev_scale_check.py"""
+run equal to the non-incremental one, timings.  usage (GPU box, not collected by pytest): python tests/manual_scale_check.py"""
 import sys, os, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "icp-variants_amd", "python"))
