@@ -5,7 +5,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 constexpr int WAVE = 64;
 constexpr int KNN_CH = 16;          // targets per filter chunk (one s_load_dwordx16 per coordinate)
-constexpr int NSUM = 40;            // doubles per block partial (34 used)
+constexpr int NSUM = 40;            // doubles per block partial (row stride of the partial / total arrays)
+constexpr int NSUM_USED = 34;       // rows the producers write and the reducer folds: count, 3 + 3 sums, 27 metric sums
 constexpr int SUM_N = 0, SUM_S = 1, SUM_D = 4, SUM_M = 7;   // count, sum s, sum d, metric-specific block
 constexpr int POST_THREADS = 256;
 

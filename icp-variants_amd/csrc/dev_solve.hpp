@@ -311,7 +311,7 @@ __device__ __forceinline__ bool solve_p2plane_lanes(const SolveParams& sp, const
     return true;
 }
 
-// Grid of NSUM blocks: block a folds the partials of sum a in a fixed order (lanes stride the producer blocks, shuffle tree,
+// Grid of NSUM_USED blocks: block a folds the partials of sum a in a fixed order (lanes stride the producer blocks, shuffle tree,
 // then the waves in order) -- identical on every run and independent of block scheduling.  The block that finishes last (ticket
 // counter, release/acquire fences at agent scope) gathers the NSUM totals and runs the small fp64 solve + pose composition.
 constexpr int SOLVE_THREADS = 256;
@@ -341,12 +341,12 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
         __hip_atomic_store(sp.totals + a, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
         const unsigned t = atomicAdd(sp.ticket, 1u);
-        is_last = (t == (unsigned)(NSUM - 1));
+        is_last = (t == (unsigned)(NSUM_USED - 1));
     }
     __syncthreads();
     if (!is_last) return;
     __threadfence();
-    if (threadIdx.x < NSUM) tot[threadIdx.x] = __hip_atomic_load(sp.totals + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < NSUM) tot[threadIdx.x] = threadIdx.x < NSUM_USED ? __hip_atomic_load(sp.totals + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;   // rows NSUM_USED.. are padding
     __syncthreads();
     if (threadIdx.x == 0) *sp.ticket = 0u;                // ready for the next launch on this stream
     if (solve_p2plane_lanes(sp, tot)) return;             // common case, spread over the lanes of this block

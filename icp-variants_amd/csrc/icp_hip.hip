@@ -84,7 +84,9 @@ struct icp_ctx {
     Cloud conv_src, conv_ref; int conv_n = 0;
     float cos_reject = 0.5f;
     std::vector<hipEvent_t> events;
+    hipEvent_t build_ev[2] = {nullptr, nullptr};   // index-build bracket (build_bvh)
     icp_timing timing;
+    std::vector<float> it_match_ms, it_post_ms, it_solve_ms;   // per iteration of the last run; -1 where the iteration was not bracketed
     std::string err;
 };
 
@@ -128,6 +130,16 @@ float compute_cos_reject() {
 }
 
 int set_device(icp_ctx* c) { HIPCK(c, hipSetDevice(c->device)); return ICP_OK; }
+
+// Every entry point that enqueues work synchronises the stream before it returns (write_pose's contract: the page-locked staging
+// area and the scratch buffers are free again by the next call).  On the success paths that is the entry point's own final
+// hipStreamSynchronize; this guard covers the error returns in between.
+struct DrainOnError {
+    icp_ctx* c; bool ok = false;
+    explicit DrainOnError(icp_ctx* ctx) : c(ctx) {}
+    ~DrainOnError() { if (!ok && c && c->stream) (void)hipStreamSynchronize(c->stream); }
+    int done(int rc = ICP_OK) { ok = (rc == ICP_OK); return rc; }
+};
 
 // Host AoS -> device SoA (+ optional padding with pad_value).
 int upload3(icp_ctx* c, const float* aos, int n, int npad, float pad_value, DevBuf& x, DevBuf& y, DevBuf& z) {
@@ -215,8 +227,9 @@ int build_query_order(icp_ctx* c, const int* d_sel, int n, DevBuf& out) {
 template <int DIM>
 int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
     int rc;
-    hipEvent_t e0, e1;
-    HIPCK(c, hipEventCreate(&e0)); HIPCK(c, hipEventCreate(&e1));
+    if (!c->build_ev[0]) HIPCK(c, hipEventCreate(&c->build_ev[0]));      // owned by the context: nothing to leak on an error return
+    if (!c->build_ev[1]) HIPCK(c, hipEventCreate(&c->build_ev[1]));
+    const hipEvent_t e0 = c->build_ev[0], e1 = c->build_ev[1];
     HIPCK(c, hipEventRecord(e0, c->stream));
     const int nv = b.n_valid;
     b.n_leaves = (nv + BVH_LEAF - 1) / BVH_LEAF;
@@ -286,7 +299,6 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
     HIPCK(c, hipEventRecord(e1, c->stream));
     HIPCK(c, hipEventSynchronize(e1));
     float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, e0, e1)); b.build_ms = ms;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     b.valid = true;
     return ICP_OK;
 }
@@ -412,15 +424,15 @@ int launch_post_and_solve(icp_ctx* c, const Cloud& src, const int* sel, int n, i
     sp.n_src = n; sp.update_pose = update_pose;
     if (p.metric == ICP_METRIC_SYMMETRIC) {
         sp.phase = 0; sp.stats = nullptr; sp.sums_out = nullptr;
-        hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM), dim3(SOLVE_THREADS), 0, c->stream, sp);       // means
+        hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM_USED), dim3(SOLVE_THREADS), 0, c->stream, sp);       // means
         hipLaunchKernelGGL(k_sym_accumulate, dim3(nb), dim3(POST_THREADS), 0, c->stream, pp);
         if (ev_after_post) HIPCK(c, hipEventRecord(ev_after_post, c->stream));
         sp.phase = 1; sp.stats = d_stats; sp.sums_out = d_sums_out;
-        hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM), dim3(SOLVE_THREADS), 0, c->stream, sp);
+        hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM_USED), dim3(SOLVE_THREADS), 0, c->stream, sp);
     } else {
         if (ev_after_post) HIPCK(c, hipEventRecord(ev_after_post, c->stream));
         sp.phase = 0; sp.stats = d_stats; sp.sums_out = d_sums_out;
-        hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM), dim3(SOLVE_THREADS), 0, c->stream, sp);
+        hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM_USED), dim3(SOLVE_THREADS), 0, c->stream, sp);
     }
     HIPCK(c, hipGetLastError());
     return ICP_OK;
@@ -579,6 +591,7 @@ int icp_ctx_destroy(icp_ctx* c) {
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->build_ev) if (e) (void)hipEventDestroy(e);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return ICP_OK;
@@ -588,7 +601,9 @@ const char* icp_last_error(const icp_ctx* c) { return c ? c->err.c_str() : "null
 
 int icp_set_params(icp_ctx* c, const icp_params* p) {
     if (!c || !p) return ICP_ERR_INVALID_ARG;
-    if (p->metric < 0 || p->metric > 2 || p->matching < 0 || p->matching > 1 || p->weighting < 0 || p->weighting > 3 || p->n_iterations < 0 || p->selection < 0 || p->selection > 1) {
+    if (p->metric < 0 || p->metric > 2 || p->matching < 0 || p->matching > 1 || p->weighting < 0 || p->weighting > 3 || p->n_iterations < 0 || p->selection < 0 || p->selection > 1 ||
+        (p->knn_backend != ICP_KNN_BRUTE_FORCE && p->knn_backend != ICP_KNN_LBVH) || p->width < 0 || p->height < 0 || (long long)p->width * p->height > 0x7FFFFFFFll ||
+        std::isnan(p->max_distance) || std::isnan(p->selection_proba) || !std::isfinite(p->fx) || !std::isfinite(p->fy) || !std::isfinite(p->cx) || !std::isfinite(p->cy)) {
         c->err = "icp_set_params: value out of range"; return ICP_ERR_INVALID_ARG;
     }
     c->prm = *p;
@@ -599,6 +614,7 @@ int icp_get_params(const icp_ctx* c, icp_params* p) { if (!c || !p) return ICP_E
 int icp_set_target(icp_ctx* c, const float* xyz, const float* normals, const uint8_t* rgba, int32_t n) {
     if (!c || !xyz || n <= 0) { if (c) c->err = "icp_set_target: null points or n <= 0"; return ICP_ERR_INVALID_ARG; }
     int rc;
+    DrainOnError guard(c);
     if ((rc = set_device(c))) return rc;
     if ((rc = upload_cloud(c, c->tgt, xyz, normals, rgba, n, true))) return rc;
     Bvh& b = c->bvh;
@@ -613,15 +629,16 @@ int icp_set_target(icp_ctx* c, const float* xyz, const float* normals, const uin
     c->bvh6.finite_idx = b.finite_idx; c->bvh6.n_valid = b.n_valid;
     b.attrs = &c->tgt; c->bvh6.attrs = &c->tgt;
     if (c->prm.knn_backend == ICP_KNN_LBVH && c->prm.matching == ICP_MATCH_KNN) {                         // buildIndex; otherwise built on first use
-        if (c->prm.color_icp && rgba) return build_bvh<6>(c, c->bvh6, target_coords6(c));
-        return build_bvh<3>(c, b, target_coords3(c));
+        if (c->prm.color_icp && rgba) return guard.done(build_bvh<6>(c, c->bvh6, target_coords6(c)));
+        return guard.done(build_bvh<3>(c, b, target_coords3(c)));
     }
-    return ICP_OK;
+    return guard.done();
 }
 
 int icp_set_source(icp_ctx* c, const float* xyz, const float* normals, const uint8_t* rgba, int32_t n) {
     if (!c || !xyz || n <= 0) { if (c) c->err = "icp_set_source: null points or n <= 0"; return ICP_ERR_INVALID_ARG; }
     int rc;
+    DrainOnError guard(c);
     if ((rc = set_device(c))) return rc;
     if ((rc = upload_cloud(c, c->src, xyz, normals, rgba, n, false))) return rc;
     c->src_valid.assign((size_t)n, 0);
@@ -634,12 +651,13 @@ int icp_set_source(icp_ctx* c, const float* xyz, const float* normals, const uin
     }
     for (auto& kv : c->levels) release(kv.second);
     c->levels.clear();
-    return ICP_OK;
+    return guard.done();
 }
 
 int icp_query_matches(icp_ctx* c, const float* transformed_xyz, const uint8_t* rgba, int32_t n, icp_match_t* out) {
     if (!c || !transformed_xyz || !out || n <= 0) { if (c) c->err = "icp_query_matches: bad argument"; return ICP_ERR_INVALID_ARG; }
     int rc;
+    DrainOnError guard(c);
     if ((rc = set_device(c))) return rc;
     if ((rc = check_ready(c, false, false))) return rc;
     const bool colors = rgba != nullptr;
@@ -652,12 +670,13 @@ int icp_query_matches(icp_ctx* c, const float* transformed_xyz, const uint8_t* r
     if ((rc = launch_match(c, q))) return rc;
     HIPCK(c, hipMemcpyAsync(out, c->matches.p, (size_t)n * sizeof(icp_match_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    return ICP_OK;
+    return guard.done();
 }
 
 int icp_match(icp_ctx* c, const float pose[16], icp_match_t* out, float* d2_out) {
     if (!c || !pose || !out) { if (c) c->err = "icp_match_t: bad argument"; return ICP_ERR_INVALID_ARG; }
     int rc;
+    DrainOnError guard(c);
     if ((rc = set_device(c))) return rc;
     if ((rc = check_ready(c, true, false))) return rc;
     if ((rc = write_pose(c, pose))) return rc;
@@ -668,12 +687,13 @@ int icp_match(icp_ctx* c, const float pose[16], icp_match_t* out, float* d2_out)
     HIPCK(c, hipMemcpyAsync(out, c->matches.p, (size_t)q.n * sizeof(icp_match_t), hipMemcpyDeviceToHost, c->stream));
     if (d2_out) HIPCK(c, hipMemcpyAsync(d2_out, c->d2.p, (size_t)q.n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    return ICP_OK;
+    return guard.done();
 }
 
 int icp_correspond(icp_ctx* c, const float pose[16], icp_match_t* out, double* sums_out, int32_t* n_valid_out) {
     if (!c || !pose) { if (c) c->err = "icp_correspond: bad argument"; return ICP_ERR_INVALID_ARG; }
     int rc;
+    DrainOnError guard(c);
     if ((rc = set_device(c))) return rc;
     if ((rc = check_ready(c, true, true))) return rc;
     if ((rc = write_pose(c, pose))) return rc;
@@ -689,7 +709,7 @@ int icp_correspond(icp_ctx* c, const float pose[16], icp_match_t* out, double* s
     HIPCK(c, hipStreamSynchronize(c->stream));
     if (sums_out) { memset(sums_out, 0, 64 * 8); memcpy(sums_out, hs, NSUM * 8); }
     if (n_valid_out) *n_valid_out = (int32_t)hs[SUM_N];
-    return ICP_OK;
+    return guard.done();
 }
 
 // Iteration schedule of LinearICPOptimizer::estimatePose: ICPOptimizer.h:503-516 (coarsest level),
@@ -720,6 +740,7 @@ static int enqueue_fontana(icp_ctx* c, float* d_out);
 static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int32_t max_stats, int32_t* n_run, bool single) {
     const icp_params& p = c->prm;
     int rc;
+    DrainOnError guard(c);
     if ((rc = set_device(c))) return rc;
     if ((rc = check_ready(c, true, true))) return rc;
     std::vector<int> factors;          // decimation factor per iteration; 0 = no selection (full cloud)
@@ -732,10 +753,11 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     }
     const int iters = (int)factors.size();
     if (n_run) *n_run = 0;
-    if (iters == 0) return ICP_OK;
+    if (iters == 0) return guard.done();
     // page-locked staging for the whole run up front: [pose state up | per-iteration records down | pose state down]
     const size_t pin_stats = 256, pin_pose = pin_stats + (((size_t)iters * sizeof(icp_iter_stats) + 255) & ~(size_t)255);
     if ((rc = ensure_pinned(c, pin_pose + 256))) return rc;
+    float pose_in[16]; memcpy(pose_in, pose_inout, 64);        // the record of an empty iteration 0 carries the incoming pose
     if ((rc = write_pose(c, pose_inout))) return rc;
     if ((rc = ensure(c, c->stats, (size_t)iters * sizeof(icp_iter_stats)))) return rc;
     // (every record of an iteration with work is written in full by k_reduce_solve; empty iterations are filled in on the host)
@@ -823,7 +845,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     memcpy(pose_inout, ((const PoseState*)((char*)c->pinned + pin_pose))->pose, 64);
     int status = ICP_OK;
     for (int i = 0; i < iters; i++) {
-        if (ns[i] <= 0) { hs[i].n_src = 0; hs[i].n_valid = 0; hs[i].status = ICP_ERR_NO_CORRESPONDENCES; memcpy(hs[i].pose, i ? hs[i - 1].pose : pose_inout, 64); hs[i].rmse = -1.f; hs[i].benchmark_error = -1.f; }
+        if (ns[i] <= 0) { hs[i].n_src = 0; hs[i].n_valid = 0; hs[i].status = ICP_ERR_NO_CORRESPONDENCES; memcpy(hs[i].pose, i ? hs[i - 1].pose : pose_in, 64); hs[i].rmse = -1.f; hs[i].benchmark_error = -1.f; }
         if (!rmse) hs[i].rmse = -1.f;
         if (!fontana) hs[i].benchmark_error = -1.f;
         if (hs[i].status != ICP_OK && status == ICP_OK) status = hs[i].status;
@@ -832,6 +854,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     if (n_run) *n_run = iters;
     icp_timing& t = c->timing; memset(&t, 0, sizeof(t)); t.iterations = iters;
     int n_sampled = 0;
+    c->it_match_ms.assign((size_t)iters, -1.f); c->it_post_ms.assign((size_t)iters, -1.f); c->it_solve_ms.assign((size_t)iters, -1.f);
     for (int i = 0; i < iters; i++) {
         if (!sampled[i]) continue;
         n_sampled++;
@@ -840,6 +863,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
         if (post_event[i]) HIPCK(c, hipEventElapsedTime(&b, E(i, 1), E(i, 2)));
         HIPCK(c, hipEventElapsedTime(&d, post_event[i] ? E(i, 2) : E(i, 1), E(i, 3)));
         t.match_ms += a; t.weight_reject_build_ms += b; t.solve_ms += d;
+        c->it_match_ms[(size_t)i] = a; c->it_post_ms[(size_t)i] = b; c->it_solve_ms[(size_t)i] = d;
         if (c->trace) fprintf(stderr, "[icp_hip] it %2d  n %d  match %.4f  post %.4f  solve %.4f ms\n", i, ns[i], a, b, d);
     }
     if (n_sampled > 0 && n_sampled < iters) {             // sampled: scale to the whole run
@@ -849,6 +873,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     t.sampled_iterations = n_sampled;
     float tot = 0; HIPCK(c, hipEventElapsedTime(&tot, c->events[0], c->events[1])); t.total_ms = tot;
     if (status != ICP_OK) c->err = "no valid correspondences in at least one iteration (reference would hang in ASSERT)";
+    guard.ok = true;                                     // synchronised above; `status` reports empty iterations, not a HIP failure
     return status;
 }
 
@@ -871,14 +896,27 @@ int icp_set_stage_timing(icp_ctx* c, int32_t every_nth) {
 
 int icp_get_timing(const icp_ctx* c, icp_timing* out) { if (!c || !out) return ICP_ERR_INVALID_ARG; *out = c->timing; return ICP_OK; }
 
+int icp_get_iteration_times(const icp_ctx* c, float* match_ms, float* weight_reject_build_ms, float* solve_ms, int32_t max_out, int32_t* count_out) {
+    if (!c || !count_out || max_out < 0) return ICP_ERR_INVALID_ARG;
+    const int n = (int)c->it_match_ms.size();
+    for (int i = 0; i < n && i < max_out; i++) {
+        if (match_ms) match_ms[i] = c->it_match_ms[(size_t)i];
+        if (weight_reject_build_ms) weight_reject_build_ms[i] = c->it_post_ms[(size_t)i];
+        if (solve_ms) solve_ms[i] = c->it_solve_ms[(size_t)i];
+    }
+    *count_out = n;
+    return ICP_OK;
+}
+
 int icp_set_convergence_reference(icp_ctx* c, const float* src_xyz, const float* ref_xyz, int32_t n) {
     if (!c || !src_xyz || !ref_xyz || n <= 0) { if (c) c->err = "icp_set_convergence_reference: bad argument"; return ICP_ERR_INVALID_ARG; }
     int rc;
+    DrainOnError guard(c);
     if ((rc = set_device(c))) return rc;
     if ((rc = upload3(c, src_xyz, n, n, 0.f, c->conv_src.x, c->conv_src.y, c->conv_src.z))) return rc;
     if ((rc = upload3(c, ref_xyz, n, n, 0.f, c->conv_ref.x, c->conv_ref.y, c->conv_ref.z))) return rc;
     c->conv_n = n;
-    return ICP_OK;
+    return guard.done();
 }
 
 static int enqueue_fontana(icp_ctx* c, float* d_out) {
@@ -898,19 +936,21 @@ int icp_benchmark_error(icp_ctx* c, const float pose[16], float* error_out) {
     if (!c || !pose || !error_out) return ICP_ERR_INVALID_ARG;
     if (c->conv_n <= 0) { c->err = "icp_benchmark_error: no convergence reference set"; return ICP_ERR_INVALID_ARG; }
     int rc;
+    DrainOnError guard(c);
     if ((rc = set_device(c))) return rc;
     if ((rc = write_pose(c, pose))) return rc;
     if ((rc = ensure(c, c->rmse_out, 4))) return rc;
     if ((rc = enqueue_fontana(c, c->rmse_out.as<float>()))) return rc;
     HIPCK(c, hipMemcpyAsync(error_out, c->rmse_out.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    return ICP_OK;
+    return guard.done();
 }
 
 int icp_rmse(icp_ctx* c, const float pose[16], float* rmse_out) {
     if (!c || !pose || !rmse_out) return ICP_ERR_INVALID_ARG;
     if (c->conv_n <= 0) { c->err = "icp_rmse: no convergence reference set"; return ICP_ERR_INVALID_ARG; }
     int rc;
+    DrainOnError guard(c);
     if ((rc = set_device(c))) return rc;
     if ((rc = write_pose(c, pose))) return rc;
     if ((rc = ensure(c, c->rmse_partials, 256 * 2 * 8))) return rc;
@@ -921,7 +961,7 @@ int icp_rmse(icp_ctx* c, const float pose[16], float* rmse_out) {
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(rmse_out, c->rmse_out.p, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    return ICP_OK;
+    return guard.done();
 }
 
 int icp_backproject_depth(icp_ctx* c, const float* depth, const uint8_t* rgbx, float fx, float fy, float cx, float cy,
@@ -929,6 +969,7 @@ int icp_backproject_depth(icp_ctx* c, const float* depth, const uint8_t* rgbx, f
                           float* xyz_out, float* normals_out, uint8_t* rgba_out, uint8_t* valid_out) {
     if (!c || !depth || !extrinsics || !xyz_out || !normals_out || width <= 0 || height <= 0) { if (c) c->err = "icp_backproject_depth: bad argument"; return ICP_ERR_INVALID_ARG; }
     int rc;
+    DrainOnError guard(c);
     if ((rc = set_device(c))) return rc;
     const size_t n = (size_t)width * height;
     // depthExtrinsics.inverse() (PointCloud.h:88-90): rigid/affine 4x4, inverted in fp64 and rounded once
@@ -941,7 +982,8 @@ int icp_backproject_depth(icp_ctx* c, const float* depth, const uint8_t* rgbx, f
     float inv[12];
     for (int i = 0; i < 9; i++) inv[i] = (float)Ri[i];
     for (int r = 0; r < 3; r++) inv[9 + r] = (float)(-(Ri[r * 3] * t[0] + Ri[r * 3 + 1] * t[1] + Ri[r * 3 + 2] * t[2]));
-    const size_t bytes = n * 4 + (rgbx ? n * 4 : 0) + 64 + n * 12 * 2 + n * 4 + n;
+    // fixed layout, colour slots always reserved: [depth 4n | rgbx 4n | inverse 64 | xyz 12n | normals 12n | rgba 4n | valid n]
+    const size_t bytes = n * 4 + n * 4 + 64 + n * 12 * 2 + n * 4 + n;
     if ((rc = ensure(c, c->staging, bytes + 256))) return rc;
     char* base = c->staging.as<char>();
     float* d_depth = (float*)base; uint8_t* d_rgbx = (uint8_t*)(base + n * 4); float* d_inv = (float*)(base + n * 8);
@@ -957,12 +999,13 @@ int icp_backproject_depth(icp_ctx* c, const float* depth, const uint8_t* rgbx, f
     if (rgbx && rgba_out) HIPCK(c, hipMemcpyAsync(rgba_out, d_rgba, n * 4, hipMemcpyDeviceToHost, c->stream));
     if (valid_out) HIPCK(c, hipMemcpyAsync(valid_out, d_valid, n, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    return ICP_OK;
+    return guard.done();
 }
 
 int icp_estimate_normals(icp_ctx* c, const float* xyz, int32_t n, int32_t k, const float viewpoint[3], float* normals_out, float* curvature_out) {
     if (!c || !xyz || !normals_out || n <= 0 || k < 3 || k > 8) { if (c) c->err = "icp_estimate_normals: bad argument (k must be 3..8)"; return ICP_ERR_INVALID_ARG; }
     int rc;
+    DrainOnError guard(c);
     if ((rc = set_device(c))) return rc;
     Cloud& cl = c->nrm_cloud; Bvh& b = c->nrm_bvh;
     if ((rc = upload_cloud(c, cl, xyz, nullptr, nullptr, n, false))) return rc;
@@ -990,12 +1033,13 @@ int icp_estimate_normals(icp_ctx* c, const float* xyz, int32_t n, int32_t k, con
     HIPCK(c, hipMemcpyAsync(normals_out, d_n, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream));
     if (curvature_out) HIPCK(c, hipMemcpyAsync(curvature_out, d_c, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    return ICP_OK;
+    return guard.done();
 }
 
 static int transform_common(icp_ctx* c, const float* in, int32_t n, const float pose[16], float* out, int normals) {
     if (!c || !in || !out || !pose || n <= 0) { if (c) c->err = "icp_transform: bad argument"; return ICP_ERR_INVALID_ARG; }
     int rc;
+    DrainOnError guard(c);
     if ((rc = set_device(c))) return rc;
     if ((rc = write_pose(c, pose))) return rc;
     if ((rc = ensure(c, c->staging, (size_t)n * 24))) return rc;
@@ -1005,7 +1049,7 @@ static int transform_common(icp_ctx* c, const float* in, int32_t n, const float 
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipMemcpyAsync(out, dout, (size_t)n * 12, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    return ICP_OK;
+    return guard.done();
 }
 int icp_transform_points(icp_ctx* c, const float* xyz, int32_t n, const float pose[16], float* out) { return transform_common(c, xyz, n, pose, out, 0); }
 int icp_transform_normals(icp_ctx* c, const float* nrm, int32_t n, const float pose[16], float* out) { return transform_common(c, nrm, n, pose, out, 1); }

@@ -18,7 +18,7 @@ MATCH_DTYPE = np.dtype([("idx", np.int32), ("weight", np.float32)])
 
 ICP_OK = 0
 ERR_NAMES = {1: "INVALID_ARG", 2: "HIP", 3: "NO_TARGET", 4: "NO_SOURCE", 5: "NO_CAMERA", 6: "TARGET_SIZE",
-             7: "COLOR_MISMATCH", 8: "NO_CORRESPONDENCES", 9: "NO_DEVICE"}
+             7: "COLOR_MISMATCH", 8: "NO_CORRESPONDENCES", 9: "NO_DEVICE", 10: "COMM"}
 ERR_NO_CORRESPONDENCES = 8
 
 
@@ -47,11 +47,21 @@ class IcpTiming(C.Structure):
                 ("total_ms", C.c_double), ("iterations", C.c_int32), ("sampled_iterations", C.c_int32)]
 
 
+class IcpPair(C.Structure):
+    _fields_ = [("src_xyz", C.c_void_p), ("src_normals", C.c_void_p), ("src_rgba", C.c_void_p), ("n_src", C.c_int32),
+                ("tgt_xyz", C.c_void_p), ("tgt_normals", C.c_void_p), ("tgt_rgba", C.c_void_p), ("n_tgt", C.c_int32),
+                ("initial_pose", C.c_float * 16)]
+
+
+COMM_ID_BYTES = 128
+
 # every symbol include/icp_hip.h declares (tests check the library exports all of them)
 EXPORTS = ["icp_ctx_create", "icp_ctx_create_on_stream", "icp_ctx_destroy", "icp_last_error", "icp_params_default",
            "icp_set_params", "icp_get_params", "icp_set_target", "icp_set_source", "icp_query_matches", "icp_match",
-           "icp_correspond", "icp_iterate", "icp_run", "icp_get_timing", "icp_set_stage_timing", "icp_set_convergence_reference", "icp_rmse", "icp_benchmark_error",
-           "icp_transform_points", "icp_transform_normals", "icp_version", "icp_schedule", "icp_select_hash", "icp_backproject_depth", "icp_estimate_normals"]
+           "icp_correspond", "icp_iterate", "icp_run", "icp_get_timing", "icp_get_iteration_times", "icp_set_stage_timing", "icp_set_convergence_reference", "icp_rmse", "icp_benchmark_error",
+           "icp_transform_points", "icp_transform_normals", "icp_version", "icp_schedule", "icp_select_hash", "icp_backproject_depth", "icp_estimate_normals",
+           "icp_batch_run", "icp_pair_owner", "icp_pairs_of_rank", "icp_comm_unique_id", "icp_comm_create", "icp_comm_destroy", "icp_gather_poses",
+           "icp_comm_last_error"]
 
 _lib = None
 
@@ -64,6 +74,9 @@ def load_library():
         _lib = C.CDLL(LIB_PATH)
         _lib.icp_last_error.restype = C.c_char_p
         _lib.icp_version.restype = C.c_char_p
+        _lib.icp_comm_last_error.restype = C.c_char_p
+        _lib.icp_pair_owner.restype = C.c_int32
+        _lib.icp_pairs_of_rank.restype = C.c_int32
     return _lib
 
 
@@ -190,6 +203,13 @@ class Context:
         return dict(match_ms=t.match_ms, weight_reject_build_ms=t.weight_reject_build_ms, solve_ms=t.solve_ms,
                     total_ms=t.total_ms, iterations=t.iterations, sampled_iterations=t.sampled_iterations)
 
+    def iteration_times(self, max_out=4096):
+        """Per-iteration (match, weight/reject/build, solve) device milliseconds of the last run; -1 = iteration not bracketed."""
+        a = np.empty(max_out, np.float32); b = np.empty(max_out, np.float32); d = np.empty(max_out, np.float32); n = C.c_int32(0)
+        self._ck(self.lib.icp_get_iteration_times(self.h, _ptr(a), _ptr(b), _ptr(d), C.c_int32(max_out), C.byref(n)))
+        k = min(n.value, max_out)
+        return a[:k].copy(), b[:k].copy(), d[:k].copy()
+
     def set_stage_timing(self, every_nth):
         """0: whole-run time only; 1: HIP events around every iteration's stages (default); N > 1: every Nth iteration, scaled."""
         self._ck(self.lib.icp_set_stage_timing(self.h, C.c_int32(int(every_nth))))
@@ -236,6 +256,83 @@ class Context:
         x = _f32(nrm); out = np.empty_like(x)
         self._ck(self.lib.icp_transform_normals(self.h, _ptr(x), C.c_int32(len(x)), _ptr(pose_to_c(pose)), _ptr(out)))
         return out
+
+
+def pair_owner(pair, n_ranks):
+    return int(load_library().icp_pair_owner(C.c_int32(pair), C.c_int32(n_ranks)))
+
+
+def pairs_of_rank(n_pairs, rank, n_ranks):
+    return int(load_library().icp_pairs_of_rank(C.c_int32(n_pairs), C.c_int32(rank), C.c_int32(n_ranks)))
+
+
+def batch_run(contexts, pairs, initial_poses=None):
+    """icp_batch_run: aligns `pairs` (dicts with src_pts/src_nrm[/src_rgba]/tgt_pts/tgt_nrm[/tgt_rgba]) on the given contexts of
+    one device, one host thread per context inside the library.  Returns ((n,16) float32 column-major poses in pair order,
+    per-pair status codes, overall status)."""
+    lib = load_library()
+    n = len(pairs)
+    keep = []                                                            # keeps the converted arrays alive for the call
+    arr = (IcpPair * max(n, 1))()
+    for i, d in enumerate(pairs):
+        def cv(key, dt):
+            a = d.get(key)
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=dt); keep.append(a)
+            return a.ctypes.data
+        arr[i].src_xyz = cv("src_pts", np.float32); arr[i].src_normals = cv("src_nrm", np.float32); arr[i].src_rgba = cv("src_rgba", np.uint8)
+        arr[i].tgt_xyz = cv("tgt_pts", np.float32); arr[i].tgt_normals = cv("tgt_nrm", np.float32); arr[i].tgt_rgba = cv("tgt_rgba", np.uint8)
+        arr[i].n_src = len(d["src_pts"]); arr[i].n_tgt = len(d["tgt_pts"])
+        p0 = pose_to_c(np.eye(4) if initial_poses is None else initial_poses[i])
+        for k in range(16):
+            arr[i].initial_pose[k] = float(p0[k])
+    hs = (C.c_void_p * len(contexts))(*[c.h for c in contexts])
+    poses = np.zeros((n, 16), np.float32); status = np.zeros(n, np.int32)
+    rc = lib.icp_batch_run(hs, C.c_int32(len(contexts)), arr, C.c_int32(n), _ptr(poses), _ptr(status))
+    return poses, status, rc
+
+
+class Comm:
+    """icp_comm: one RCCL communicator per process / GPU; the unique id travels through the host application."""
+
+    def __init__(self, device, n_ranks, rank, unique_id):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        self.n_ranks, self.rank = n_ranks, rank
+        idb = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        rc = self.lib.icp_comm_create(C.c_int(device), C.c_int32(n_ranks), C.c_int32(rank), idb, C.byref(self.h))
+        if rc != ICP_OK:
+            self.h = None
+            raise IcpError(rc, self.lib.icp_comm_last_error().decode())
+
+    @staticmethod
+    def unique_id():
+        lib = load_library()
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        rc = lib.icp_comm_unique_id(buf)
+        if rc != ICP_OK:
+            raise IcpError(rc, lib.icp_comm_last_error().decode())
+        return bytes(buf)
+
+    def gather_poses(self, local_poses, n_pairs):
+        lp = np.ascontiguousarray(np.asarray(local_poses, np.float32).reshape(-1, 16))
+        out = np.zeros((n_pairs, 16), np.float32)
+        rc = self.lib.icp_gather_poses(self.h, _ptr(lp) if len(lp) else None, C.c_int32(len(lp)), C.c_int32(n_pairs), _ptr(out))
+        if rc != ICP_OK:
+            raise IcpError(rc, self.lib.icp_comm_last_error().decode())
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.icp_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class LinearICPOptimizer:

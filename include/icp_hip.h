@@ -42,7 +42,8 @@ enum icp_status {
     ICP_ERR_TARGET_SIZE = 6,         /* "Invalid size of target points"            NearestNeighbor.h:346-349 */
     ICP_ERR_COLOR_MISMATCH = 7,      /* 3-D index queried with colours or vice versa NearestNeighbor.h:149-152,240-243 */
     ICP_ERR_NO_CORRESPONDENCES = 8,  /* reference ASSERT (ICPOptimizer.h:668,680,788) -- reported, never a hang */
-    ICP_ERR_NO_DEVICE = 9
+    ICP_ERR_NO_DEVICE = 9,
+    ICP_ERR_COMM = 10                /* RCCL missing or an RCCL call failed; see icp_comm_last_error() */
 };
 
 /* enum values mirror the reference */
@@ -136,6 +137,10 @@ int icp_correspond(icp_ctx* ctx, const float pose[16], icp_match_t* out, double*
 int icp_iterate(icp_ctx* ctx, float pose_inout[16], icp_iter_stats* stats);
 int icp_run(icp_ctx* ctx, float pose_inout[16], icp_iter_stats* stats, int32_t max_stats, int32_t* n_iterations_run);
 int icp_get_timing(const icp_ctx* ctx, icp_timing* out);
+/* The same breakdown iteration by iteration for the last icp_run (what TimeMeasure accumulates, before the sum): entry i is the
+ * device time of iteration i in milliseconds, or -1 when that iteration was not bracketed (icp_set_stage_timing(N != 1)).  Any of
+ * the three arrays may be NULL; *count_out = iterations of the last run. */
+int icp_get_iteration_times(const icp_ctx* ctx, float* match_ms, float* weight_reject_build_ms, float* solve_ms, int32_t max_out, int32_t* count_out);
 /* How icp_run fills the stage breakdown: 0 = whole-run time only, 1 = every iteration bracketed by HIP events (default;
  * what TimeMeasure does), N > 1 = every Nth iteration (rotating offset), stage sums scaled by iterations / sampled.
  * A HIP event costs about 4 us of stream time, i.e. mode 1 is ~10 % of a 0.07 ms iteration. */
@@ -175,6 +180,41 @@ int icp_estimate_normals(icp_ctx* ctx, const float* xyz, int32_t n, int32_t k, c
 /* The selection predicate of RANDOM_SAMPLING: point `index` is kept in resample number `iteration` iff the returned
  * 32-bit hash is < proba * 2^32.  Exposed so host code (and the test oracle) can reproduce the device's choice exactly. */
 uint32_t icp_select_hash(uint32_t seed, uint32_t iteration, uint32_t index);
+
+/* -------- batches of independent scan pairs: the loop over ETH indices, main.cpp:411-498 / experiment.cpp:319-396 --------
+ * The reference aligns the pairs one after the other and carries no state between them, so a batch shards with no
+ * data-path exchange: pair p belongs to rank p % n_ranks (icp_pair_owner), and the only collective is ONE gather of the
+ * 16-float poses at the end of the batch. */
+typedef struct icp_pair {
+    const float* src_xyz; const float* src_normals; const uint8_t* src_rgba; int32_t n_src;   /* input.source, borrowed for the call */
+    const float* tgt_xyz; const float* tgt_normals; const uint8_t* tgt_rgba; int32_t n_tgt;   /* input.target */
+    float initial_pose[16];                                                                  /* estimatedPose on entry (main.cpp:416) */
+} icp_pair;
+
+/* Aligns pairs[0..n_pairs) with the contexts ctxs[0..n_ctx) of ONE device: one host thread per context (a context is
+ * single-threaded, contexts are independent), each taking the next pair not yet started -- while one pair iterates, the
+ * uploads, index builds and iterations of the others overlap on their own HIP streams.  Every context runs with its own
+ * icp_params (set them beforehand).  poses_out: n_pairs x 16 floats, column-major, in pair order; status_out (optional):
+ * per-pair ICP_OK / error code.  Returns ICP_OK or the first error in pair order. */
+int icp_batch_run(icp_ctx* const* ctxs, int32_t n_ctx, const icp_pair* pairs, int32_t n_pairs, float* poses_out, int32_t* status_out);
+
+/* Round-robin ownership of the batch: rank of pair p, and the number of pairs a rank owns. */
+int32_t icp_pair_owner(int32_t pair, int32_t n_ranks);
+int32_t icp_pairs_of_rank(int32_t n_pairs, int32_t rank, int32_t n_ranks);
+
+/* Pose gather across the GPUs of a node: one RCCL communicator (one rank per process / GPU, xGMI), ONE ncclAllGather of
+ * ceil(n_pairs / n_ranks) x 16 floats per rank and batch.  RCCL (librccl.so.1) is loaded on first use, the library has no
+ * link-time dependency on it.  The unique id is created on one rank and shipped to the others by the host application
+ * (MPI, a file, torch.distributed, ...), exactly like ncclGetUniqueId / ncclCommInitRank. */
+typedef struct icp_comm icp_comm;
+enum { ICP_COMM_ID_BYTES = 128 };
+int icp_comm_unique_id(uint8_t id_out[ICP_COMM_ID_BYTES]);
+int icp_comm_create(int device, int32_t n_ranks, int32_t rank, const uint8_t id[ICP_COMM_ID_BYTES], icp_comm** out);
+int icp_comm_destroy(icp_comm* comm);
+/* local_poses: this rank's poses in the order of its pairs (rank, rank + n_ranks, ...), n_local = icp_pairs_of_rank(...);
+ * all_poses_out: n_pairs x 16 floats in pair order, identical on every rank. */
+int icp_gather_poses(icp_comm* comm, const float* local_poses, int32_t n_local, int32_t n_pairs, float* all_poses_out);
+const char* icp_comm_last_error(void);
 
 /* Library identification: returns e.g. "icp_hip gfx950 <build id>". */
 const char* icp_version(void);

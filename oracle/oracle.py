@@ -17,18 +17,31 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "icp_oracle.cpp")
 _LIB = os.path.join(_HERE, "_build", "libicp_oracle.so")
+_LIB_SAN = os.path.join(_HERE, "_build", "libicp_oracle_san.so")
+# ICP_ORACLE_SANITIZE=1: load the -fsanitize=address,undefined build ("race detection / sanitizers").  The process
+# must then run with LD_PRELOAD=<libasan.so> -- tests/test_sanitize.py starts such a child for tests/test_oracle.py.
+SANITIZE = os.environ.get("ICP_ORACLE_SANITIZE", "0") == "1"
 
 MATCH_DTYPE = np.dtype([("idx", np.int32), ("weight", np.float32)])
 
 
-def build(force=False):
-    """Compile the oracle with the flags its arithmetic contract requires."""
-    if not force and os.path.exists(_LIB) and (not os.path.exists(_SRC) or os.path.getmtime(_LIB) >= os.path.getmtime(_SRC)):
-        return _LIB
-    os.makedirs(os.path.dirname(_LIB), exist_ok=True)
-    cmd = ["g++", "-O2", "-std=c++14", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-o", _LIB, _SRC]
+def build(force=False, sanitize=None):
+    """Compile the oracle with the flags its arithmetic contract requires.  sanitize=True: the AddressSanitizer +
+    UndefinedBehaviourSanitizer build (same arithmetic flags, -O1 -g, every UB report fatal)."""
+    sanitize = SANITIZE if sanitize is None else sanitize
+    out = _LIB_SAN if sanitize else _LIB
+    if not force and os.path.exists(out) and (not os.path.exists(_SRC) or os.path.getmtime(out) >= os.path.getmtime(_SRC)):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    opt = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"] if sanitize else ["-O2"]
+    cmd = ["g++"] + opt + ["-std=c++14", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-o", out, _SRC]
     subprocess.check_call(cmd)
-    return _LIB
+    return out
+
+
+def sanitizer_preload():
+    """LD_PRELOAD value a (non-instrumented) Python needs before it can load the sanitized oracle."""
+    return subprocess.check_output(["g++", "-print-file-name=libasan.so"]).decode().strip()
 
 
 class Params(C.Structure):
@@ -65,8 +78,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_LIB)
+        _lib = C.CDLL(build())
         _lib.orc_rmse.restype = C.c_float
         _lib.orc_select_hash.restype = C.c_uint
         _lib.orc_benchmark_error.restype = C.c_double

@@ -12,7 +12,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 def header_functions():
     txt = open(os.path.join(ROOT, "include", "icp_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"^\s*(?:int|uint32_t|const char\s*\*)\s+(icp_\w+)\s*\(", txt, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|int32_t|uint32_t|const char\s*\*)\s+(icp_\w+)\s*\(", txt, flags=re.M)))
 
 
 def test_header_and_binding_agree():

@@ -64,3 +64,29 @@ def test_single_process_path():
     from icp_amd import batch
     res = batch.align_batch(3, _fake_pose)
     assert np.array_equal(res, np.stack([_fake_pose(p) for p in range(3)]))
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it must start 2 ranks (here: --dry-run, gloo, no device) and report
+    n_gpus = 2; a WORLD_SIZE that disagrees with --gpus is refused."""
+    import json, subprocess, sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1                                              # exactly ONE JSON line on stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["gather_ok"] is True
+    env["WORLD_SIZE"] = "1"
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert bad.returncode != 0 and b"refusing" in bad.stderr
+
+
+def test_cabi_shard_rule_matches_python():
+    from icp_amd import batch, binding
+    for n_pairs, world in ((44, 8), (7, 2), (3, 4), (0, 2)):
+        for r in range(world):
+            assert binding.pairs_of_rank(n_pairs, r, world) == len(batch.shard_pairs(n_pairs, r, world))
+        assert [binding.pair_owner(p, world) for p in range(n_pairs)] == [p % world for p in range(n_pairs)]
