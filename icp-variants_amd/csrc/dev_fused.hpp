@@ -1,0 +1,221 @@
+// dev_fused.hpp -- the fused matcher k_knn_bvh_post: exact BVH 1-NN + weight / reject / accumulate + (optionally) the reduction of
+// the block partials, the linear solve and the pose update, all in ONE launch per ICP iteration.
+// Part of icp_device.hpp (included from there, inside namespace icpdev); see that file for the build contract.
+// ------------------------------------------------------------------------------------------------
+// BVH k-NN with the post stage as its epilogue: the lane that found the neighbour of query k immediately weighs / rejects /
+// accumulates it, so matches never make a round trip through memory.  One kernel instead of two per iteration.  Each lane
+// has at most one pair: its contributions are produced two at a time and fed straight into the first step of the transposing
+// wave reduction, which keeps the kernel at the register budget of the walk.  Block partials keep the fixed-order contract.
+struct RowSlotGen {                                       // value A = slot A of one pair's point-to-plane rows
+    const RowTerms& R; bool valid;
+    static constexpr int N = 27;
+    template <int A> __device__ __forceinline__ double get() const { return valid ? row_slot<A>(R) : 0.0; }
+};
+struct P2pGen {                                           // values 0..21 = sum s (3), sum d (3), then SUM_M + 0..15 of post_core's point-to-point block
+    float s[3], d[3]; double wd; bool valid;
+    static constexpr int N = 22;
+    template <int A> __device__ __forceinline__ double get() const {
+        double v;
+        if constexpr (A < 3) v = (double)s[A];
+        else if constexpr (A < 6) v = (double)d[A - 3];
+        else if constexpr (A == 6) v = wd;
+        else if constexpr (A < 10) v = wd * s[A - 7];
+        else if constexpr (A < 13) v = wd * d[A - 10];
+        else v = (double)d[(A - 13) / 3] * (wd * s[(A - 13) % 3]);
+        return valid ? v : 0.0;
+    }
+};
+// Reduction of the block partials + solve INSIDE the matcher's launch (no k_reduce_solve launch, no second kernel boundary per
+// iteration).  Two levels of "last arriver folds": the blocks of a group of FUSE_GROUP consecutive logical blocks publish their 34
+// sums and take a ticket; the block that takes the group's last ticket adds the group's partials in block order, publishes the
+// group sums and takes a ticket of the second level; the last of those adds the group sums in group order -- fixed orders, so
+// the totals do not depend on who arrives when -- and runs the solve (solve_tail) for the whole launch.
+// Cross-workgroup visibility on this multi-XCD part (MI355X_MICROARCH.md, "Valid forms"): every published byte is stored with an
+// agent-scope atomic store (write-through, sc1), the storing wave drains its stores (s_waitcnt vmcnt(0)) before ONE of its lanes
+// adds to the ticket counter (agent-scope atomic), and every load of published bytes is an agent-scope atomic load (sc1) issued
+// after the add has returned.  No release / acquire fence: a fence would write back or invalidate a whole L2 per block, which is
+// what made the first attempt at this (round 1: __threadfence() per block) 2.5 x slower than the two-kernel form.
+constexpr int FUSE_GROUP = 64;
+// Register budget of the fused matcher: the tree walk + epilogue fit 80 VGPRs (6 waves per SIMD for DIM 3; the 6-D walk needs 106:
+// 4 waves).  The solve code at the end of the kernel runs in ONE block per launch and may spill under this cap; the walk does not.
+template <int DIM> struct FusedWaves { static constexpr int v = DIM == 3 ? 6 : 4; };
+#define FUSED_WAVES_PER_SIMD FusedWaves<DIM>::v
+struct FuseTail {
+    int enabled;                 // 0: block partials in k_reduce_solve's layout, nothing else
+    double* block_partials;      // [gridDim.x][NSUM_USED] by logical block
+    double* group_partials;      // [ceil(gridDim.x / FUSE_GROUP)][NSUM_USED]
+    unsigned int* tickets;       // [0] second level, [1 + g] group g; all zero between launches (the last arriver resets them)
+    SolveParams sp;
+};
+__device__ __forceinline__ double ld_pub(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_pub(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// sum of `count` published rows (stride NSUM_USED doubles) in row order, eight loads in flight at a time
+__device__ __forceinline__ double fold_pub(const double* src, int count) {
+    double acc = 0.0;
+    for (int b0 = 0; b0 < count; b0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (b0 + u < count) ? ld_pub(src + (size_t)(b0 + u) * NSUM_USED) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (b0 + u < count) acc += v[u];
+    }
+    return acc;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(BVH_THREADS) __attribute__((amdgpu_waves_per_eu(FUSED_WAVES_PER_SIMD, FUSED_WAVES_PER_SIMD))) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp, const FuseTail ft) {
+    extern __shared__ uint2 bvh_lbq[];                    // [Lq][BVH_THREADS] pending-sibling bounds; reused by the reduction
+    constexpr int NW = BVH_THREADS / WAVE;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS + tid;
+    const int k = (t < kp.n) ? (qorder ? qorder[t] : t) : -1;
+    bool valid = false;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, wt = 0.f;
+    float p[DIM];
+#pragma unroll
+    for (int q = 0; q < DIM; q++) p[q] = 0.f;
+    float rn0 = 0.f, rn1 = 0.f, rn2 = 0.f;
+    float best = FLT_MAX, lb_others = 0.f; int bi = -1, bpos = -1, q0 = -1;
+    float4 ra, rb; ra.x = 0.f; ra.y = 0.f; ra.z = 0.f; ra.w = 0.f; rb = ra;
+    bool need_walk = false, verified = false;
+    if (k >= 0) {
+        // ---- front end.  Everything that depends only on the query index is requested in ONE batch (point, normal, previous
+        // neighbour, search state), then the neighbour's record: two memory round trips before the verify test instead of
+        // one per array -- in the late iterations, where almost no query walks, those round trips ARE the kernel.
+        const int i = kp.sel ? kp.sel[k] : k;
+        const float r0 = kp.sx[i], r1 = kp.sy[i], r2 = kp.sz[i];
+        if (DIM == 6) { p[3 % DIM] = kp.scr[i]; p[4 % DIM] = kp.scg[i]; p[5 % DIM] = kp.scb[i]; }
+        rn0 = pp.snx[i]; rn1 = pp.sny[i]; rn2 = pp.snz[i];
+        const bool seeded = kp.use_prev != 0, inc = kp.incremental && seeded;
+        q0 = seeded ? kp.nn_raw[k] : -1;
+        float4 st; st.x = 0.f; st.y = 0.f; st.z = 0.f; st.w = 0.f;
+        if (inc) st = kp.qstate[k];
+        xform_point(kp.ps->pose, r0, r1, r2, p[0], p[1], p[2]);
+        if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
+            need_walk = true;
+            if (q0 >= 0) {                                 // seed_from_previous + knn_try_verify, on the batched loads
+                float tq[DIM]; int j0;
+                if (DIM == 3) { ra = *(const float4*)(bv.recs + q0); rb = *((const float4*)(bv.recs + q0) + 1); tq[0] = ra.x; tq[1] = ra.y; tq[2] = ra.z; j0 = __float_as_int(ra.w); }
+                else {
+                    const BvhLeafT<DIM>* lf = bv.leaves + (q0 >> 3);
+#pragma unroll
+                    for (int q = 0; q < DIM; q++) tq[q] = lf->c[q][q0 & 7];
+                    j0 = lf->idx[q0 & 7];
+                }
+                float d = 0.f;
+#pragma unroll
+                for (int q = 0; q < DIM; q++) { const float e = p[q] - tq[q]; d = (q == 0) ? e * e : d + e * e; }
+                if (d < best) { best = d; bi = j0; bpos = q0; }
+                if (inc && bi >= 0) {
+                    const float ex = p[0] - st.x, ey = p[1] - st.y, ez = p[2] - st.z;
+                    const float delta = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.000001f + 1e-30f;
+                    const float lbn = (st.w - delta) * 0.999999f;
+                    if (sqrtf(best) * 1.000001f < lbn) { lb_others = lbn; need_walk = false; verified = true; }
+                }
+            }
+        }
+    }
+    // ---- the walks.  A wave left with only a few seeded queries to search does them cooperatively, one after the other
+    // (coop_search); otherwise every lane walks on its own.
+    {
+        unsigned long long wm = __ballot(need_walk);
+        const unsigned long long cm = __ballot(need_walk && bpos >= 0);
+        if (ICP_COOP_MAX > 0 && wm != 0ull && wm == cm && __popcll(wm) <= ICP_COOP_MAX && bv.Lq > 0) {
+            const int lane = tid & 63;
+            while (wm) {
+                const int src = __ffsll((long long)wm) - 1; wm &= wm - 1ull;
+                float q[DIM];
+#pragma unroll
+                for (int a = 0; a < DIM; a++) q[a] = __shfl(p[a], src, WAVE);
+                float b = __shfl(best, src, WAVE), lbo = 0.f; int ci = __shfl(bi, src, WAVE), cps = __shfl(bpos, src, WAVE);
+                const bool done = coop_search<DIM, BVH_THREADS>(bv, q, b, ci, cps, lbo, bvh_lbq, tid);      // wave-uniform
+                if (done && lane == src) { best = b; bi = ci; bpos = cps; lb_others = lbo; need_walk = false; }
+            }
+        }
+    }
+    if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, bvh_lbq, tid);
+    if (k >= 0) {
+        // A verified query keeps its stored anchor (position of the last full search) and bound: the triangle test stays valid
+        // against the OLD anchor -- and is tighter than re-anchoring, (L - d1) - d2 <= L - |d1 + d2| -- and its neighbour is
+        // unchanged, so nothing of its search state needs rewriting.  Once ICP has converged that is > 99.9 % of the queries:
+        // the 28 B per query of state stores (and the Match record, when nobody reads it) disappear from those launches.
+        if (!verified) knn_store_state<DIM>(kp, k, p, best, bpos, lb_others);
+        else if (kp.d2_out) kp.d2_out[k] = best;
+        icp_match_t m;
+        if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
+        if (m.idx < 0) { if (pp.matches) pp.matches[k] = m; }
+        else {
+            if (DIM != 3 || bpos != q0) { ra = *(const float4*)(bv.recs + bpos); rb = *((const float4*)(bv.recs + bpos) + 1); }      // one 32-byte record
+            d0 = ra.x; d1 = ra.y; d2 = ra.z; n0 = rb.x; n1 = rb.y; n2 = rb.z;
+            s0 = p[0]; s1 = p[1]; s2 = p[2];
+            valid = post_eval<true>(pp, k, m, d0, d1, d2, n0, n1, n2, __float_as_uint(rb.w), s0, s1, s2, wt, rn0, rn1, rn2);
+        }
+    }
+    __syncthreads();                                      // the traversal stacks are dead: reuse LDS for the reduction
+    // ---- epilogue: the block's sums.  Every lane has at most one pair; its <= 27 contributions are folded over the wave with
+    // the transposing reduction (wave_transpose_reduce_from: permlane swaps + DPP, no LDS traffic), the two wave totals meet in
+    // LDS, and threads 0..33 write the block partial in the fixed slot order the reducer expects.
+    double* lds = (double*)bvh_lbq;                       // [NW][32] wave totals, then [NW] counts
+    double tot;
+    if (pp.metric == ICP_METRIC_POINT_TO_PLANE) {
+        RowTerms R;
+        build_rows(0, s0, s1, s2, d0, d1, d2, n0, n1, n2, wt, R);
+        const RowSlotGen g{R, valid};                     // 27 slots of [J^T J | J^T r]
+        tot = wave_transpose_reduce_gen<6, 0>(g, lane);
+    } else {                                              // point-to-point moments (see post_core): sum s, sum d, then the 16 weighted ones
+        const P2pGen g{{s0, s1, s2}, {d0, d1, d2}, (double)wt, valid};
+        tot = wave_transpose_reduce_gen<6, 0>(g, lane);
+    }
+    {
+        const unsigned long long vm = __ballot(valid);    // the count is an integer: one ballot per wave
+        const int v = wave_value_of_lane(lane);
+        if (v < 32) lds[w * 32 + v] = tot;                // values past the last one are exact zeros
+        if (lane == 0) lds[NW * 32 + w] = (double)__popcll(vm);
+    }
+    __syncthreads();
+    const int nb = gridDim.x, lb = xcd_contiguous_block(blockIdx.x, nb);         // partial slot = logical block -> fixed summation order
+    if (tid < NSUM_USED) {                                // threads 0..33: this block's sum `tid`
+        double out = 0.0;
+        if (tid == SUM_N) { for (int ww = 0; ww < NW; ww++) out += lds[NW * 32 + ww]; }
+        else {
+            // point-to-plane: slots SUM_M.. <- values 0..26 (the sums of s and d feed only the means: not needed, zero);
+            // point-to-point: slots 1..22 <- values 0..21
+            const int v = pp.metric == ICP_METRIC_POINT_TO_PLANE ? tid - SUM_M : tid - 1;
+            const int nv = pp.metric == ICP_METRIC_POINT_TO_PLANE ? 27 : 22;
+            if (v >= 0 && v < nv) { for (int ww = 0; ww < NW; ww++) out += lds[ww * 32 + v]; }
+        }
+        if (ft.enabled) st_pub(ft.block_partials + (size_t)lb * NSUM_USED + tid, out);
+        else pp.partials[(size_t)tid * nb + lb] = out;
+    }
+    if (!ft.enabled) return;
+    __shared__ double s_tot[NSUM];
+    __shared__ int s_final;
+    if (w == 0) {                                         // threads 0..33 live in wave 0: the whole hand-over is this wave's business
+        const int g = lb / FUSE_GROUP, ng = (nb + FUSE_GROUP - 1) / FUSE_GROUP;
+        const int gcount = min(FUSE_GROUP, nb - g * FUSE_GROUP);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned int t = 0u;
+        if (tid == 0) t = __hip_atomic_fetch_add(ft.tickets + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+        int fin = 0;
+        if (t == (unsigned int)(gcount - 1)) {            // last block of the group (wave-uniform)
+            if (tid < NSUM_USED) st_pub(ft.group_partials + (size_t)g * NSUM_USED + tid, fold_pub(ft.block_partials + (size_t)g * FUSE_GROUP * NSUM_USED + tid, gcount));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned int t2 = 0u;
+            if (tid == 0) {
+                __hip_atomic_store(ft.tickets + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // ready for the next launch
+                t2 = __hip_atomic_fetch_add(ft.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            t2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)t2);
+            if (t2 == (unsigned int)(ng - 1)) {           // last group: the totals, then the solve
+                const double tot_a = tid < NSUM_USED ? fold_pub(ft.group_partials + tid, ng) : 0.0;
+                if (tid < NSUM) s_tot[tid] = tot_a;
+                if (tid == 0) __hip_atomic_store(ft.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fin = 1;
+            }
+        }
+        if (tid == 0) s_final = fin;
+    }
+    __syncthreads();
+    if (s_final) solve_tail<false>(ft.sp, s_tot);         // the symmetric metric never takes this path (it needs the means first)
+}

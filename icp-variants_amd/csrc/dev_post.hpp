@@ -53,6 +53,76 @@ __device__ __forceinline__ double block_reduce_wide(double (&v)[NV], double* lds
     return tot;
 }
 
+
+// ---- wave-level TRANSPOSING reduction of N doubles per lane, in registers --------------------------------------------------
+// A shuffle tree folds every value over all 64 lanes: 6 steps x N values, each step a cross-lane permute.  Here every step
+// halves the NUMBER of values a lane holds instead: the two halves of the lane set exchange the values the other half keeps
+// (lanes with the step's bit clear keep value 2j and receive the partner's copy of it, lanes with the bit set keep value 2j+1),
+// so N values cost N/2 + N/4 + ... exchanges, and the steps over lane bits 5 and 4 are v_permlane32_swap / v_permlane16_swap
+// (gfx950, plain VALU) instead of trips through the LDS crossbar; bits 3..0 are DPP row operations.  At the end value v sits,
+// summed over the whole wave, in the lanes whose bits (5,4,3,2,1,0) spell (v0,v1,v2,v3,v4,v5) -- see wave_value_of_lane.
+// The pairing is fixed, so the sums are bitwise reproducible.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int dbl_lo(double v) { return (unsigned int)(unsigned long long)__double_as_longlong(v); }
+__device__ __forceinline__ unsigned int dbl_hi(double v) { return (unsigned int)((unsigned long long)__double_as_longlong(v) >> 32); }
+__device__ __forceinline__ double dbl_from(unsigned int lo, unsigned int hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); }
+
+// lanes 0-31 / even rows end up with a (own + partner's), lanes 32-63 / odd rows with b
+template <int SPAN>
+__device__ __forceinline__ double swap_add(double a, double b) {
+    u32x2 r0, r1;
+    if (SPAN == 32) { r0 = __builtin_amdgcn_permlane32_swap(dbl_lo(a), dbl_lo(b), false, false); r1 = __builtin_amdgcn_permlane32_swap(dbl_hi(a), dbl_hi(b), false, false); }
+    else            { r0 = __builtin_amdgcn_permlane16_swap(dbl_lo(a), dbl_lo(b), false, false); r1 = __builtin_amdgcn_permlane16_swap(dbl_hi(a), dbl_hi(b), false, false); }
+    return dbl_from(r0[0], r1[0]) + dbl_from(r0[1], r1[1]);
+}
+// DPP controls that pair lanes across bit 3 (row_mirror), 2 (row_half_mirror), 1 and 0 (quad permutes)
+template <int BIT> struct DppCtrl { static constexpr int v = BIT == 3 ? 0x140 : BIT == 2 ? 0x141 : BIT == 1 ? 0x4E : 0xB1; };
+template <int BIT>
+__device__ __forceinline__ double dpp_add(double a, double b, int lane) {
+    const bool up = (lane >> BIT) & 1;
+    const double send = up ? a : b, keep = up ? b : a;
+    const double recv = dbl_from((unsigned int)__builtin_amdgcn_update_dpp(0, (int)dbl_lo(send), DppCtrl<BIT>::v, 0xF, 0xF, false),
+                                 (unsigned int)__builtin_amdgcn_update_dpp(0, (int)dbl_hi(send), DppCtrl<BIT>::v, 0xF, 0xF, false));
+    return keep + recv;
+}
+template <int STEP, int N>                        // STEP 0..5 <-> lane bit 5..0
+__device__ __forceinline__ double wave_transpose_reduce_from(double (&x)[N], int lane) {
+    if constexpr (STEP == 6) { static_assert(N == 1, "at most 64 values"); return x[0]; }
+    else {
+        constexpr int H = (N + 1) / 2;
+        double y[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) {
+            const double a = x[2 * j], b = (2 * j + 1 < N) ? x[2 * j + 1] : 0.0;
+            if constexpr (STEP == 0) y[j] = swap_add<32>(a, b);
+            else if constexpr (STEP == 1) y[j] = swap_add<16>(a, b);
+            else y[j] = dpp_add<5 - STEP>(a, b, lane);
+        }
+        return wave_transpose_reduce_from<STEP + 1, H>(y, lane);
+    }
+}
+// The same reduction evaluated depth-first over a value GENERATOR (f.get<A>() produces value A): group (K, BASE) = the 2^K values
+// from BASE on, folded through steps 0..K-1.  Only one partial per level is alive at any time -- O(log N) registers instead of
+// N / 2 -- which is what lets the fused matcher keep the register budget of the tree walk.  Same pairing, same result.
+template <int K, int BASE, class F>
+__device__ __forceinline__ double wave_transpose_reduce_gen(const F& f, int lane) {
+    if constexpr (K == 0) return f.template get<BASE>();
+    else {
+        constexpr int HALF = 1 << (K - 1);
+        const double a = wave_transpose_reduce_gen<K - 1, BASE>(f, lane);
+        double b = 0.0;                                   // a group past the last value is an exact zero, the exchange still runs
+        if constexpr (BASE + HALF < F::N) b = wave_transpose_reduce_gen<K - 1, BASE + HALF>(f, lane);
+        if constexpr (K == 3) __builtin_amdgcn_sched_barrier(0);       // keeps the generator's products from being hoisted across groups
+        if constexpr (K == 1) return swap_add<32>(a, b);
+        else if constexpr (K == 2) return swap_add<16>(a, b);
+        else return dpp_add<6 - K>(a, b, lane);
+    }
+}
+// index of the value whose wave total this lane holds after the reduction (values >= N: zero)
+__device__ __forceinline__ int wave_value_of_lane(int lane) {
+    return ((lane >> 5) & 1) | (((lane >> 4) & 1) << 1) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 3) | (((lane >> 1) & 1) << 4) | ((lane & 1) << 5);
+}
+
 // Rows of the reference's 4n x 6 system in fp32 (kind 0: point-to-plane, ICPOptimizer.h:698-750; kind 1: symmetric,
 // ICPOptimizer.h:806-852, s/d already centred, n = n_t + n_s).  Row 0 is dense and scaled by LAMBDA_PLANE/SYMMETRIC = 1 times
 // the weight; rows 1-3 are the point rows [0, s2, -s1, 1,0,0 | d0-s0], [-s2, 0, s0, 0,1,0 | d1-s1], [s1, -s0, 0, 0,0,1 | d2-s2]
@@ -141,7 +211,7 @@ struct PostParams {
     const float* tx; const float* ty; const float* tz;
     const float* tnx; const float* tny; const float* tnz; const uint32_t* trgba;
     const PoseState* ps;
-    icp_match_t* matches;          // in: after matching; out: after weighting + pruning
+    icp_match_t* matches;          // in: after matching; out: after weighting + pruning.  The fused matcher may get nullptr (records not kept)
     int metric, weighting, rejection;
     float max_dist, cos_reject;  // cos_reject: largest float c with acosf(c) > 60 deg on this host's libm
     double* partials;            // [NSUM][gridDim.x]: sum a of block b at a * gridDim.x + b (the reducer reads rows contiguously)
@@ -196,7 +266,7 @@ __device__ __forceinline__ bool post_eval(const PostParams& pp, int k, icp_match
         // acos(c) > 60deg  <=>  -1 <= c <= cos_reject ; NaN / |c| > 1 => acos is NaN => kept
         if (c >= -1.0f && c <= pp.cos_reject) m.idx = -1;
     }
-    pp.matches[k] = m;
+    if (pp.matches) pp.matches[k] = m;                     // nullptr: nobody reads the records (fused point-to-point / point-to-plane loop)
     w = m.weight;
     return m.idx >= 0 && fin_sd;                           // ICPOptimizer.h:596-598
 }
@@ -239,188 +309,6 @@ __global__ __launch_bounds__(POST_THREADS) void k_post(const PostParams pp) {
     if (threadIdx.x < 34) pp.partials[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = tot;
 }
 
-// BVH k-NN with the post stage as its epilogue: the lane that found the neighbour of query k immediately weighs / rejects /
-// accumulates it, so matches never make a round trip through memory.  One kernel instead of two per iteration.  Each lane
-// has exactly one pair, so the 34 sums are not accumulated in registers first: every value is produced, folded 64 -> 16 lanes
-// with two shuffles and parked in LDS right away (groups separated by scheduling barriers), which keeps the kernel at the
-// register budget of the walk.  Block partials keep the fixed-order reduction contract.
-// N values at a time, stage by stage (all shuffles of a stage in flight together: the cross-lane permutes have ~100 cycles of
-// latency each, a value-by-value chain would expose 2 x 34 of them per wave).
-template <int N>
-__device__ __forceinline__ void fold_store_n(double (&x)[N], double* lds, int a0, int lane, int w) {
-    double y[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) y[i] = __shfl_down(x[i], 32, WAVE);
-#pragma unroll
-    for (int i = 0; i < N; i++) x[i] += y[i];
-#pragma unroll
-    for (int i = 0; i < N; i++) y[i] = __shfl_down(x[i], 16, WAVE);
-#pragma unroll
-    for (int i = 0; i < N; i++) x[i] += y[i];
-    if (lane < 16) {
-#pragma unroll
-        for (int i = 0; i < N; i++) lds[(w * 34 + a0 + i) * 17 + lane] = x[i];
-    }
-}
-template <int A, int N, int I = 0>
-__device__ __forceinline__ void row_slots_n(const RowTerms& R, bool valid, double (&x)[N]) {
-    if constexpr (I < N) { x[I] = valid ? row_slot<A + I>(R) : 0.0; row_slots_n<A, N, I + 1>(R, valid, x); }
-}
-template <int A, int N>
-__device__ __forceinline__ void fold_row_slots(const RowTerms& R, bool valid, double* lds, int lane, int w) {
-    double x[N];
-    row_slots_n<A, N>(R, valid, x);
-    fold_store_n<N>(x, lds, SUM_M + A, lane, w);
-}
-template <int DIM>
-__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {
-    extern __shared__ uint2 bvh_lbq[];                    // [Lq][BVH_THREADS] pending-sibling bounds; reused by the reduction
-    constexpr int NW = BVH_THREADS / WAVE;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS + tid;
-    const int k = (t < kp.n) ? (qorder ? qorder[t] : t) : -1;
-    bool valid = false;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, wt = 0.f;
-    float p[DIM];
-#pragma unroll
-    for (int q = 0; q < DIM; q++) p[q] = 0.f;
-    float rn0 = 0.f, rn1 = 0.f, rn2 = 0.f;
-    float best = FLT_MAX, lb_others = 0.f; int bi = -1, bpos = -1, q0 = -1;
-    float4 ra, rb; ra.x = 0.f; ra.y = 0.f; ra.z = 0.f; ra.w = 0.f; rb = ra;
-    bool need_walk = false;
-    if (k >= 0) {
-        // ---- front end.  Everything that depends only on the query index is requested in ONE batch (point, normal, previous
-        // neighbour, search state), then the neighbour's record: two memory round trips before the verify test instead of
-        // one per array -- in the late iterations, where almost no query walks, those round trips ARE the kernel.
-        const int i = kp.sel ? kp.sel[k] : k;
-        const float r0 = kp.sx[i], r1 = kp.sy[i], r2 = kp.sz[i];
-        if (DIM == 6) { p[3 % DIM] = kp.scr[i]; p[4 % DIM] = kp.scg[i]; p[5 % DIM] = kp.scb[i]; }
-        rn0 = pp.snx[i]; rn1 = pp.sny[i]; rn2 = pp.snz[i];
-        const bool seeded = kp.use_prev != 0, inc = kp.incremental && seeded;
-        q0 = seeded ? kp.nn_raw[k] : -1;
-        float4 st; st.x = 0.f; st.y = 0.f; st.z = 0.f; st.w = 0.f;
-        if (inc) st = kp.qstate[k];
-        xform_point(kp.ps->pose, r0, r1, r2, p[0], p[1], p[2]);
-        if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
-            need_walk = true;
-            if (q0 >= 0) {                                 // seed_from_previous + knn_try_verify, on the batched loads
-                float tq[DIM]; int j0;
-                if (DIM == 3) { ra = *(const float4*)(bv.recs + q0); rb = *((const float4*)(bv.recs + q0) + 1); tq[0] = ra.x; tq[1] = ra.y; tq[2] = ra.z; j0 = __float_as_int(ra.w); }
-                else {
-                    const BvhLeafT<DIM>* lf = bv.leaves + (q0 >> 3);
-#pragma unroll
-                    for (int q = 0; q < DIM; q++) tq[q] = lf->c[q][q0 & 7];
-                    j0 = lf->idx[q0 & 7];
-                }
-                float d = 0.f;
-#pragma unroll
-                for (int q = 0; q < DIM; q++) { const float e = p[q] - tq[q]; d = (q == 0) ? e * e : d + e * e; }
-                if (d < best) { best = d; bi = j0; bpos = q0; }
-                if (inc && bi >= 0) {
-                    const float ex = p[0] - st.x, ey = p[1] - st.y, ez = p[2] - st.z;
-                    const float delta = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.000001f + 1e-30f;
-                    const float lbn = (st.w - delta) * 0.999999f;
-                    if (sqrtf(best) * 1.000001f < lbn) { lb_others = lbn; need_walk = false; }
-                }
-            }
-        }
-    }
-    // ---- the walks.  A wave left with only a few seeded queries to search does them cooperatively, one after the other
-    // (coop_search); otherwise every lane walks on its own.
-    {
-        unsigned long long wm = __ballot(need_walk);
-        const unsigned long long cm = __ballot(need_walk && bpos >= 0);
-        if (ICP_COOP_MAX > 0 && wm != 0ull && wm == cm && __popcll(wm) <= ICP_COOP_MAX && bv.Lq > 0) {
-            const int lane = tid & 63;
-            while (wm) {
-                const int src = __ffsll((long long)wm) - 1; wm &= wm - 1ull;
-                float q[DIM];
-#pragma unroll
-                for (int a = 0; a < DIM; a++) q[a] = __shfl(p[a], src, WAVE);
-                float b = __shfl(best, src, WAVE), lbo = 0.f; int ci = __shfl(bi, src, WAVE), cps = __shfl(bpos, src, WAVE);
-                const bool done = coop_search<DIM, BVH_THREADS>(bv, q, b, ci, cps, lbo, bvh_lbq, tid);      // wave-uniform
-                if (done && lane == src) { best = b; bi = ci; bpos = cps; lb_others = lbo; need_walk = false; }
-            }
-        }
-    }
-    if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, bvh_lbq, tid);
-    if (k >= 0) {
-        knn_store_state<DIM>(kp, k, p, best, bpos, lb_others);
-        icp_match_t m;
-        if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
-        if (m.idx < 0) pp.matches[k] = m;
-        else {
-            if (DIM != 3 || bpos != q0) { ra = *(const float4*)(bv.recs + bpos); rb = *((const float4*)(bv.recs + bpos) + 1); }      // one 32-byte record
-            d0 = ra.x; d1 = ra.y; d2 = ra.z; n0 = rb.x; n1 = rb.y; n2 = rb.z;
-            s0 = p[0]; s1 = p[1]; s2 = p[2];
-            valid = post_eval<true>(pp, k, m, d0, d1, d2, n0, n1, n2, __float_as_uint(rb.w), s0, s1, s2, wt, rn0, rn1, rn2);
-        }
-    }
-    __syncthreads();                                      // the traversal stacks are dead: reuse LDS for the reduction
-    double* lds = (double*)bvh_lbq;
-    {   // the count is an integer: one ballot per wave, stored as lane 0's "partial" (the other 15 are zero)
-        const unsigned long long vm = __ballot(valid);
-        if (lane < 16) lds[(w * 34 + SUM_N) * 17 + lane] = (lane == 0) ? (double)__popcll(vm) : 0.0;
-    }
-    if (pp.metric == ICP_METRIC_POINT_TO_PLANE) {
-        // the sums of s and d feed only the means (point-to-point / symmetric): not needed here, their slots stay zero
-        if (lane < 16) {
-#pragma unroll
-            for (int q = 0; q < 6; q++) lds[(w * 34 + SUM_S + q) * 17 + lane] = 0.0;
-        }
-    } else {
-        double x[6] = {valid ? (double)s0 : 0.0, valid ? (double)s1 : 0.0, valid ? (double)s2 : 0.0,
-                       valid ? (double)d0 : 0.0, valid ? (double)d1 : 0.0, valid ? (double)d2 : 0.0};
-        fold_store_n<6>(x, lds, SUM_S, lane, w);          // SUM_S.., SUM_D.. are slots 1..6
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (pp.metric == ICP_METRIC_POINT_TO_PLANE) {
-        RowTerms R;
-        build_rows(0, s0, s1, s2, d0, d1, d2, n0, n1, n2, wt, R);
-        fold_row_slots<0, 7>(R, valid, lds, lane, w);   __builtin_amdgcn_sched_barrier(0);
-        fold_row_slots<7, 7>(R, valid, lds, lane, w);   __builtin_amdgcn_sched_barrier(0);
-        fold_row_slots<14, 7>(R, valid, lds, lane, w);  __builtin_amdgcn_sched_barrier(0);
-        fold_row_slots<21, 6>(R, valid, lds, lane, w);
-    } else {                                              // point-to-point moments (see post_core)
-        const double wd = (double)wt;
-        const double ws[3] = {wd * s0, wd * s1, wd * s2};
-        const float dd[3] = {d0, d1, d2};
-        {
-            double x[7] = {valid ? wd : 0.0, valid ? ws[0] : 0.0, valid ? ws[1] : 0.0, valid ? ws[2] : 0.0,
-                           valid ? wd * dd[0] : 0.0, valid ? wd * dd[1] : 0.0, valid ? wd * dd[2] : 0.0};
-            fold_store_n<7>(x, lds, SUM_M, lane, w);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            double x[9];
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-#pragma unroll
-                for (int q = 0; q < 3; q++) x[j * 3 + q] = valid ? (double)dd[j] * ws[q] : 0.0;
-            }
-            fold_store_n<9>(x, lds, SUM_M + 7, lane, w);
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int q = 16; q < 27; q++) lds[(w * 34 + SUM_M + q) * 17 + lane] = 0.0;
-        }
-    }
-    __syncthreads();
-    if (tid < 34) {
-        double tot = 0.0;
-#pragma unroll
-        for (int ww = 0; ww < NW; ww++) {
-            const double* row = lds + (ww * 34 + tid) * 17;
-            double part = 0.0;
-#pragma unroll
-            for (int l = 0; l < 16; l++) part += row[l];
-            tot += part;
-        }
-        const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);             // partial slot = logical block -> fixed summation order
-        pp.partials[(size_t)tid * gridDim.x + lb] = tot;
-    }
-}
-
 // Second pass of the symmetric objective: rows need the means of the valid pairs first
 // (ICPOptimizer.h:797-809).  Reads the final matches written by k_post.
 __global__ __launch_bounds__(POST_THREADS) void k_sym_accumulate(const PostParams pp) {
@@ -447,4 +335,17 @@ __global__ __launch_bounds__(POST_THREADS) void k_sym_accumulate(const PostParam
     }
     const double tot = block_reduce_wide<27, 4>(acc, lds);
     if (threadIdx.x < 27) pp.partials[(size_t)(SUM_M + threadIdx.x) * gridDim.x + blockIdx.x] = tot;
+}
+
+// Hardware self test of wave_transpose_reduce_gen (icp_selftest_wave_reduce, tests/test_gpu_selftest.py).
+struct ArrayGen27 { const double* x; static constexpr int N = 27; template <int A> __device__ __forceinline__ double get() const { return x[A]; } };
+__global__ void k_selftest_wave_reduce(const double* __restrict__ in /* [64][27] */, double* __restrict__ out /* [27] */, int* __restrict__ lane_of /* [27] */) {
+    const int lane = threadIdx.x & 63;
+    double x[27];
+#pragma unroll
+    for (int a = 0; a < 27; a++) x[a] = in[lane * 27 + a];
+    const ArrayGen27 g{x};
+    const double tot = wave_transpose_reduce_gen<6, 0>(g, lane);
+    const int v = wave_value_of_lane(lane);
+    if (v < 27) { out[v] = tot; lane_of[v] = lane; }
 }

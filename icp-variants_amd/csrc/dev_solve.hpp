@@ -103,7 +103,9 @@ __device__ __forceinline__ bool solve_ldlt6(const double* sums, double* x) {
 
 __device__ inline void solve_normal_svd(const double* sums /* 21 + 6 */, double* x) {
     if (solve_ldlt6(sums, x)) return;
-    double A[36], V[36], ev[6];
+    // workspaces in LDS, not in registers / scratch: this runs on ONE thread, and inside the fused matcher it must not raise the
+    // kernel's register or scratch footprint (a dispatch with a large scratch demand stalls the queue)
+    __shared__ double A[36], V[36], ev[6];
     int q = 0;
     for (int a = 0; a < 6; a++) for (int c = a; c < 6; c++) { A[a * 6 + c] = sums[q]; A[c * 6 + a] = sums[q]; q++; }
     const double* g = sums + 21;
@@ -155,12 +157,11 @@ __device__ inline void solve_fullpiv_lu6(double* M, double* rhs, double* x, int*
 //   R = U_0 V_0^T + U_1 V_1^T + det(V) * c * V_2^T
 // (flipping the sign of the third left vector flips det(UV^T) too), which stays well defined when sigma_3 -> 0.
 __device__ inline void procrustes_rotation(const double* A /* 3x3 row-major */, double* R) {
-    double B[9], V[9], ev[3];
+    __shared__ double B[9], V[9], ev[3], Vs[9], U[9];     // LDS workspaces (single thread): see solve_normal_svd
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += A[k * 3 + i] * A[k * 3 + j]; B[i * 3 + j] = s; }
     jacobi_eig_sym<3>(B, V, ev);
     int o[3] = {0, 1, 2};
     for (int a = 0; a < 2; a++) for (int b = a + 1; b < 3; b++) if (ev[o[b]] > ev[o[a]]) { const int t = o[a]; o[a] = o[b]; o[b] = t; }
-    double Vs[9], U[9];
     for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) Vs[r * 3 + c] = V[r * 3 + o[c]];
     const double s0 = sqrt(fmax(ev[o[0]], 0.0));
     for (int c = 0; c < 2; c++) {
@@ -311,46 +312,12 @@ __device__ __forceinline__ bool solve_p2plane_lanes(const SolveParams& sp, const
     return true;
 }
 
-// Grid of NSUM_USED blocks: block a folds the partials of sum a in a fixed order (lanes stride the producer blocks, shuffle tree,
-// then the waves in order) -- identical on every run and independent of block scheduling.  The block that finishes last (ticket
-// counter, release/acquire fences at agent scope) gathers the NSUM totals and runs the small fp64 solve + pose composition.
-constexpr int SOLVE_THREADS = 256;
-__global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParams sp) {
-    __shared__ double tot[NSUM];
-    __shared__ double wsum[SOLVE_THREADS / WAVE];
-    __shared__ int is_last;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, a = blockIdx.x;
-    {
-        const double* __restrict__ row = sp.partials + (size_t)a * sp.nblocks;
-        // four independent running sums per thread (fixed assignment): the loads of one round are in flight together
-        double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
-        int b = threadIdx.x;
-        for (; b + 3 * SOLVE_THREADS < sp.nblocks; b += 4 * SOLVE_THREADS) {
-            const double v0 = row[b], v1 = row[b + SOLVE_THREADS], v2 = row[b + 2 * SOLVE_THREADS], v3 = row[b + 3 * SOLVE_THREADS];
-            x0 += v0; x1 += v1; x2 += v2; x3 += v3;
-        }
-        for (; b < sp.nblocks; b += SOLVE_THREADS) x0 += row[b];
-        double x = (x0 + x1) + (x2 + x3);
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
-        if (lane == 0) wsum[w] = x;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double x = wsum[0];
-        for (int k = 1; k < SOLVE_THREADS / WAVE; k++) x += wsum[k];
-        __hip_atomic_store(sp.totals + a, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        const unsigned t = atomicAdd(sp.ticket, 1u);
-        is_last = (t == (unsigned)(NSUM_USED - 1));
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    if (threadIdx.x < NSUM) tot[threadIdx.x] = threadIdx.x < NSUM_USED ? __hip_atomic_load(sp.totals + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;   // rows NSUM_USED.. are padding
-    __syncthreads();
-    if (threadIdx.x == 0) *sp.ticket = 0u;                // ready for the next launch on this stream
-    if (solve_p2plane_lanes(sp, tot)) return;             // common case, spread over the lanes of this block
-    if (threadIdx.x != 0) return;
+// The single-thread part of the solve (every metric, and point-to-plane when a pivot fails the rank test): thread 0 of the block
+// that holds the NSUM totals in `tot` (shared memory).  (A real call would not help the fused matcher, which inlines it too: on
+// AMDGPU a kernel reserves the registers of everything it may call -- 254 here.  The matcher caps its own budget instead, so this
+// cold code spills there rather than costing the tree walk a wave per SIMD.)
+template <bool WITH_SYMMETRIC>
+__device__ inline void solve_generic(const SolveParams& sp, const double* tot) {
     if (sp.sums_out) for (int a = 0; a < NSUM; a++) sp.sums_out[a] = tot[a];
     PoseState* ps = sp.ps;
     const double n = tot[SUM_N];
@@ -383,10 +350,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
         // A = sum_i (d_i - dm)(w_i (s_i - sm))^T expanded in moments (ProcrustesAligner.h:50-55)
         const double* m = tot + SUM_M;
         const float msf[3] = {ps->mean_s[0], ps->mean_s[1], ps->mean_s[2]}, mdf[3] = {ps->mean_d[0], ps->mean_d[1], ps->mean_d[2]};
-        double A[9];
+        __shared__ double A[9], Rd[9];
         for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++)
             A[j * 3 + k] = m[7 + j * 3 + k] - m[4 + j] * (double)msf[k] - (double)mdf[j] * m[1 + k] + m[0] * (double)mdf[j] * (double)msf[k];
-        double Rd[9]; float R[9];
+        float R[9];
         procrustes_rotation(A, Rd);
         for (int i = 0; i < 9; i++) R[i] = (float)Rd[i];
         const float tr[3] = {mdf[0] - msf[0], mdf[1] - msf[1], mdf[2] - msf[2]};     // ProcrustesAligner.h:70
@@ -397,7 +364,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
             t[r] = (Rt - Rm) + mdf[r];                                             // ProcrustesAligner.h:26
         }
         set_pose_f32(dT, R, t);
-    } else {
+    } else if constexpr (WITH_SYMMETRIC) {
         // symmetric: M = A^T A + lambda^2 I, FullPivLU (ICPOptimizer.h:858-868)
         __shared__ double M[36], g[6], x[6], ywork[6];
         __shared__ int colp[6];
@@ -439,4 +406,52 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
         sp.stats->benchmark_error = -1.f;
         sp.stats->status = status;
     }
+}
+
+// Reduced sums -> pose update.  All threads of the block call it (>= 64 threads); `tot` = NSUM totals in shared memory.
+template <bool WITH_SYMMETRIC = true>
+__device__ __forceinline__ void solve_tail(const SolveParams& sp, const double* tot) {
+    if (solve_p2plane_lanes(sp, tot)) return;             // common case, spread over the lanes of this block
+    if (threadIdx.x == 0) solve_generic<WITH_SYMMETRIC>(sp, tot);
+}
+
+// Grid of NSUM_USED blocks: block a folds the partials of sum a in a fixed order (lanes stride the producer blocks, shuffle tree,
+// then the waves in order) -- identical on every run and independent of block scheduling.  The block that finishes last (ticket
+// counter, release/acquire fences at agent scope) gathers the NSUM totals and runs the small fp64 solve + pose composition.
+constexpr int SOLVE_THREADS = 256;
+__global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParams sp) {
+    __shared__ double tot[NSUM];
+    __shared__ double wsum[SOLVE_THREADS / WAVE];
+    __shared__ int is_last;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, a = blockIdx.x;
+    {
+        const double* __restrict__ row = sp.partials + (size_t)a * sp.nblocks;
+        // four independent running sums per thread (fixed assignment): the loads of one round are in flight together
+        double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
+        int b = threadIdx.x;
+        for (; b + 3 * SOLVE_THREADS < sp.nblocks; b += 4 * SOLVE_THREADS) {
+            const double v0 = row[b], v1 = row[b + SOLVE_THREADS], v2 = row[b + 2 * SOLVE_THREADS], v3 = row[b + 3 * SOLVE_THREADS];
+            x0 += v0; x1 += v1; x2 += v2; x3 += v3;
+        }
+        for (; b < sp.nblocks; b += SOLVE_THREADS) x0 += row[b];
+        double x = (x0 + x1) + (x2 + x3);
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
+        if (lane == 0) wsum[w] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double x = wsum[0];
+        for (int k = 1; k < SOLVE_THREADS / WAVE; k++) x += wsum[k];
+        __hip_atomic_store(sp.totals + a, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const unsigned t = atomicAdd(sp.ticket, 1u);
+        is_last = (t == (unsigned)(NSUM_USED - 1));
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (threadIdx.x < NSUM) tot[threadIdx.x] = threadIdx.x < NSUM_USED ? __hip_atomic_load(sp.totals + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;   // rows NSUM_USED.. are padding
+    __syncthreads();
+    if (threadIdx.x == 0) *sp.ticket = 0u;                // ready for the next launch on this stream
+    solve_tail(sp, tot);
 }

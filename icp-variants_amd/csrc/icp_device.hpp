@@ -7,7 +7,7 @@
 // fp32 sqrt and divide are correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
 //
 // Files: dev_common.hpp, dev_knn_brute.hpp, dev_bvh.hpp, dev_normals.hpp, dev_projective.hpp, dev_post.hpp, dev_solve.hpp,
-// dev_measures.hpp (included below, in this order, inside namespace icpdev).
+// dev_fused.hpp, dev_measures.hpp (included below, in this order, inside namespace icpdev).
 //
 // Kernel map (reference file:line relative to icp-variants/ of the reference):
 //   k_deinterleave      AoS -> SoA upload conversion (+ colour features NearestNeighbor.h:212-221)
@@ -41,6 +41,7 @@ namespace icpdev {
 #include "dev_projective.hpp"
 #include "dev_post.hpp"
 #include "dev_solve.hpp"
+#include "dev_fused.hpp"
 #include "dev_measures.hpp"
 
 }  // namespace icpdev

@@ -159,7 +159,7 @@ def test_bench_eth_dir_is_one_command(tmp_path):
     """`python bench.py --eth-dir DIR` runs the files end to end and says so in its JSON line."""
     _write_eth_dataset(tmp_path, n_pairs=1)
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--eth-dir", str(tmp_path), "--steps", "2", "--warmup", "1",
-                                   "--no-cpu-baseline"], timeout=600).decode()
+                                   "--stage-timing", "1", "--no-cpu-baseline"], timeout=600).decode()
     line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
     assert line["data"] == "eth" and line["n_gpus"] == 1 and line["value"] > 0
     assert "apartment_global.csv" in line["config"]["workload"] and line["n_valid_last"] > 1000
