@@ -40,6 +40,24 @@ typedef BvhLeafT<3> BvhLeaf;
 // that chain, not by bytes or flops.
 template <int DIM> struct BvhQuadT { float lo[DIM][4]; float hi[DIM][4]; float pad[DIM == 3 ? 8 : 16]; };   // padded to one / two 128-byte lines
 
+// Quantised form of the same 4-wide node (ICP_QUANT_NODES=1): the child boxes on a uniform 14-bit grid over the bounding box of the
+// tree, 2 bytes per bound -- 48 B instead of 96 B per 3-D node, three 16-byte loads per lane and step instead of six.  The walk is
+// bound by the number of divergent 16-byte loads the texture path has to serve (every lane reads its own node) and by the latency of
+// that queue, not by arithmetic.  Conservative by construction: lower bounds are rounded down and upper bounds up (with a margin
+// that covers the fp32 rounding of the grid mapping), the query is widened to the grid cell interval that contains it, and the box
+// distance is evaluated in integer arithmetic (saturating packed u16 subtractions, exact squares, exact sums) -- so the bound never
+// exceeds the true box distance and the search stays exact; a box is only ever visited a little earlier than with fp32 boxes.
+// Layout: lo[k][0] = children (0, 1) as two u16 in one dword, lo[k][1] = children (2, 3); likewise hi.  An EMPTY child has
+// lo[0] = 0xFFFF, hi[0] = 0 and neutral other axes: its "distance" is >= QEMPTY_ACC, which no real box can reach.
+#ifndef ICP_QUANT_NODES
+#define ICP_QUANT_NODES 0
+#endif
+constexpr int QGRID_MAX = (1 << 14) - 1;                   // grid coordinates 0 .. 16383: 6 x 16383^2 < 2^31 <= QEMPTY_ACC <= 65535^2 < 2^32
+constexpr unsigned int QEMPTY_ACC = 0x80000000u;
+struct BvhGrid { float origin[6]; float inv_delta; float delta2; float pad[8]; };      // grid coordinate g = (x - origin) * inv_delta; delta2 = cell size squared
+template <int DIM> struct BvhQuadQT { unsigned int lo[DIM][2]; unsigned int hi[DIM][2]; unsigned int pad[DIM == 3 ? 4 : 8]; };   // 64 B / 128 B
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
 // Everything the loop needs about a matched target point in ONE 32-byte record, stored in kd (leaf) order -- position
 // pos = 8 * leaf + slot.  Neighbouring (Morton-sorted) queries match neighbouring positions, so the gather of the
 // correspondence (point, normal, colour) is one sector per query instead of seven scattered planes.
@@ -52,6 +70,8 @@ template <int DIM> struct BvhViewT {
     const BvhNodeT<DIM>* nodes;   // [Lp - 1] internal nodes in heap order (node k: children 2k+1, 2k+2; leaves start at Lp-1)
     const TgtRec* recs;           // [8 * max(n_leaves,1)] point + normal + colour + original index by position
     const BvhQuadT<DIM>* qnodes;  // [(4^Lq - 1) / 3] 4-wide nodes, level l at offset (4^l - 1) / 3; the children of level Lq - 1 are the leaves
+    const BvhQuadQT<DIM>* qq;     // the same nodes quantised (ICP_QUANT_NODES)
+    const BvhGrid* grid;          // ... and their grid
     int Lq;                       // 4-wide levels = ceil(log2(Lp) / 2)  (an odd binary depth gets a virtual root with one empty half)
     int n_valid;                  // finite target points in the tree
     int Lp;                       // leaves rounded up to a power of two
@@ -306,6 +326,46 @@ __global__ void k_bvh_quad_nodes(const BvhNodeT<DIM>* __restrict__ nodes, int pa
     for (int k = 0; k < DIM; k++) { qnodes[q].lo[k][c] = lo[k]; qnodes[q].hi[k][c] = hi[k]; }
 }
 
+// Grid of the quantised nodes: uniform cell size over the root box (two cells of slack on every side).
+template <int DIM>
+__global__ void k_bvh_grid(const BvhNodeT<DIM>* __restrict__ nodes, BvhGrid* __restrict__ grid) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float ext = 0.f, lo[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; k++) {
+        lo[k] = fminf(nodes[0].lo[k][0], nodes[0].lo[k][1]);
+        const float hi = fmaxf(nodes[0].hi[k][0], nodes[0].hi[k][1]);
+        ext = fmaxf(ext, hi - lo[k]);
+    }
+    float delta = ext / (float)(QGRID_MAX - 4);
+    if (!(delta > 0.f) || !isfinite(delta)) delta = 1.f;
+    const float inv = 1.f / delta;
+    for (int k = 0; k < 6; k++) grid->origin[k] = k < DIM ? lo[k] - 2.f * delta : 0.f;
+    grid->inv_delta = inv;
+    const double d = 1.0 / (double)inv;                   // the cell size the stored inverse stands for
+    grid->delta2 = (float)(d * d);
+}
+__device__ __forceinline__ float grid_coord(const BvhGrid* __restrict__ g, int k, float x) { return (x - g->origin[k]) * g->inv_delta; }
+template <int DIM>
+__global__ void k_bvh_quantize(const BvhQuadT<DIM>* __restrict__ qnodes, int n_nodes, const BvhGrid* __restrict__ grid, BvhQuadQT<DIM>* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_nodes * 4) return;
+    const int q = t >> 2, c = t & 3;
+    const bool empty = !(qnodes[q].lo[0][c] <= qnodes[q].hi[0][c]);
+#pragma unroll
+    for (int k = 0; k < DIM; k++) {
+        int l, h;
+        if (empty) { l = k == 0 ? 0xFFFF : 0; h = k == 0 ? 0 : 0xFFFF; }
+        else {
+            // 0.05 cells of margin: the fp32 error of grid_coord is below 0.01 cells at the far end of the grid
+            l = (int)floorf(grid_coord(grid, k, qnodes[q].lo[k][c]) - 0.05f); h = (int)ceilf(grid_coord(grid, k, qnodes[q].hi[k][c]) + 0.05f);
+            l = min(max(l, 0), QGRID_MAX); h = min(max(h, 0), QGRID_MAX);
+        }
+        ((unsigned short*)&out[q].lo[k][0])[c] = (unsigned short)l;
+        ((unsigned short*)&out[q].hi[k][0])[c] = (unsigned short)h;
+    }
+}
+
 // Lower bounds of the fp32 squared distance from the query to any point of the two child boxes, both at once (packed
 // f32), accumulated in the SAME order as the point distance: ((e0^2 + e1^2) + e2^2) [+ e3^2 + e4^2 + e5^2].
 template <int DIM>
@@ -413,6 +473,58 @@ __device__ __forceinline__ void quad_lb(const BvhQuadT<DIM>* __restrict__ nd, co
     }
 }
 
+// The query as the node tests need it: packed fp32 pairs for the leaves (and the fp32 nodes), the grid cell interval for the
+// quantised nodes (low half = floor, high half = ceil, margins as in k_bvh_quantize).
+template <int DIM> struct QueryPt {
+    f2 p2[DIM];
+#if ICP_QUANT_NODES
+    unsigned int pq[DIM]; float delta2;
+#endif
+};
+template <int DIM>
+__device__ __forceinline__ void make_query(const BvhViewT<DIM>& bv, const float* p, QueryPt<DIM>& q) {
+#pragma unroll
+    for (int k = 0; k < DIM; k++) { q.p2[k].x = p[k]; q.p2[k].y = p[k]; }
+#if ICP_QUANT_NODES
+    const BvhGrid* __restrict__ g = bv.grid;
+    q.delta2 = g->delta2;
+#pragma unroll
+    for (int k = 0; k < DIM; k++) {
+        const float gq = fminf(fmaxf(grid_coord(g, k, p[k]), -1.f), (float)QGRID_MAX + 1.f);      // a query outside the grid clamps towards it: still conservative
+        const int l = min(max((int)floorf(gq - 0.05f), 0), QGRID_MAX), h = min(max((int)ceilf(gq + 0.05f), 0), QGRID_MAX);
+        q.pq[k] = (unsigned int)l | ((unsigned int)h << 16);
+    }
+#endif
+}
+#if ICP_QUANT_NODES
+__device__ __forceinline__ us2 as_us2(unsigned int v) { return __builtin_bit_cast(us2, v); }
+template <int DIM>
+__device__ __forceinline__ void quad_lb_q(const BvhQuadQT<DIM>* __restrict__ nd, const QueryPt<DIM>& q, f2& l01, f2& l23) {
+    unsigned int acc[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < DIM; k++) {
+        const us2 pq = as_us2(q.pq[k]);
+        const us2 pl = {pq.x, pq.x}, ph = {pq.y, pq.y};
+        const uint2 lo = *(const uint2*)nd->lo[k], hi = *(const uint2*)nd->hi[k];
+        const us2 e01 = __builtin_elementwise_max(__builtin_elementwise_sub_sat(as_us2(lo.x), ph), __builtin_elementwise_sub_sat(pl, as_us2(hi.x)));
+        const us2 e23 = __builtin_elementwise_max(__builtin_elementwise_sub_sat(as_us2(lo.y), ph), __builtin_elementwise_sub_sat(pl, as_us2(hi.y)));
+        acc[0] += (unsigned int)e01.x * (unsigned int)e01.x; acc[1] += (unsigned int)e01.y * (unsigned int)e01.y;
+        acc[2] += (unsigned int)e23.x * (unsigned int)e23.x; acc[3] += (unsigned int)e23.y * (unsigned int)e23.y;
+    }
+    l01.x = acc[0] >= QEMPTY_ACC ? INFINITY : (float)acc[0] * q.delta2; l01.y = acc[1] >= QEMPTY_ACC ? INFINITY : (float)acc[1] * q.delta2;
+    l23.x = acc[2] >= QEMPTY_ACC ? INFINITY : (float)acc[2] * q.delta2; l23.y = acc[3] >= QEMPTY_ACC ? INFINITY : (float)acc[3] * q.delta2;
+}
+#endif
+// lower bounds of the four children of 4-wide node `node` (index over all levels)
+template <int DIM>
+__device__ __forceinline__ void quad_lb_at(const BvhViewT<DIM>& bv, unsigned int node, const QueryPt<DIM>& q, f2& l01, f2& l23) {
+#if ICP_QUANT_NODES
+    quad_lb_q<DIM>(bv.qq + node, q, l01, l23);
+#else
+    quad_lb<DIM>(bv.qnodes + node, q.p2, l01, l23);
+#endif
+}
+
 // thr: prune threshold derived from the running best (see quad_run)
 __device__ __forceinline__ void quad_pop(QuadState& st, const uint2* __restrict__ lbq, int tid, int nthreads, float thr, float& minlb) {
     while (!st.alive && st.pending) {
@@ -447,9 +559,15 @@ __device__ __forceinline__ unsigned int quad_prefetch_path(const BvhViewT<DIM>& 
 #pragma unroll
     for (int u = 0; u < 8; u++) {                         // branch-free (levels above the root clamp to the root): the loads issue back to back
         const int L = max(bv.Lq - 1 - u, 0), sh = min(2 * (u + 1), 2 * bv.Lq);
+#if ICP_QUANT_NODES
+        const unsigned int* nd = (const unsigned int*)(bv.qq + ((0x5555555555555555ull & ((1ull << (2 * L)) - 1ull)) + (unsigned long long)(leaf >> sh)));
+        t[u] = nd[11];
+        if (DIM == 6) t[u] |= nd[23];
+#else
         const unsigned int* nd = (const unsigned int*)(bv.qnodes + ((0x5555555555555555ull & ((1ull << (2 * L)) - 1ull)) + (unsigned long long)(leaf >> sh)));
         t[u] = nd[31];
         if (DIM == 6) t[u] |= nd[63];
+#endif
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) sink |= t[u];
@@ -457,7 +575,7 @@ __device__ __forceinline__ unsigned int quad_prefetch_path(const BvhViewT<DIM>& 
 }
 
 template <int DIM>
-__device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const f2* p2, QuadState& st,
+__device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<DIM>& qp, QuadState& st,
                                          float& best, int& bi, int& bpos, float& best2, float& minlb, uint2* __restrict__ lbq, int tid, int nthreads) {
     const int Lq = bv.Lq;
     // A box is skipped when its lower bound exceeds thr = best * (1 + 2e-5) (clamped so that the +inf bound of an empty box is
@@ -466,7 +584,7 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const f2* p2, 
     while (st.alive) {
         while (st.alive && st.L < Lq) {
             f2 l01, l23;
-            quad_lb<DIM>(bv.qnodes + ((0x55555555u & ((1u << (2 * st.L)) - 1u)) + (unsigned int)st.idx), p2, l01, l23);
+            quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * st.L)) - 1u)) + (unsigned int)st.idx, qp, l01, l23);
             const float m = fminf(fminf(l01.x, l01.y), fminf(l23.x, l23.y));
             const bool s0 = !(l01.x > thr), s1 = !(l01.y > thr), s2 = !(l23.x > thr), s3 = !(l23.y > thr);
             minlb = fminf(minlb, fminf(fminf(s0 ? FLT_MAX : l01.x, s1 ? FLT_MAX : l01.y), fminf(s2 ? FLT_MAX : l23.x, s3 ? FLT_MAX : l23.y)));   // skipped right here
@@ -485,7 +603,7 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const f2* p2, 
             quad_pop(st, lbq, tid, nthreads, thr, minlb);
         }
         if (st.alive) {
-            leaf_eval<DIM>(bv.leaves + st.idx, st.idx, p2, best, bi, bpos, best2);
+            leaf_eval<DIM>(bv.leaves + st.idx, st.idx, qp.p2, best, bi, bpos, best2);
             thr = fminf(best * 1.00002f, FLT_MAX);
             st.alive = false;
             quad_pop(st, lbq, tid, nthreads, thr, minlb);
@@ -496,9 +614,20 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const f2* p2, 
 // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (block b runs on the XCD group b % 8), each
 // with a private 4 MiB L2.  With Morton-sorted queries, giving every XCD group ONE contiguous slice of the sorted list
 // means its L2 only has to hold the part of the tree under that slice (plus the shared top levels) instead of all of it.
+#ifndef ICP_XCD_CHUNK
+#define ICP_XCD_CHUNK 0          // 0: one contiguous slice per XCD group; C > 0: slices of C consecutive blocks dealt round-robin (load balance vs locality)
+#endif
 __device__ __forceinline__ int xcd_contiguous_block(int b, int nb) {
+#if ICP_XCD_CHUNK > 0
+    constexpr int C = ICP_XCD_CHUNK;
+    const int full = (nb / (8 * C)) * (8 * C);           // the part that divides evenly; the rest keeps its place
+    if (b >= full) return b;
+    const int x = b & 7, j = b >> 3;
+    return (j / C) * (8 * C) + x * C + (j % C);
+#else
     const int q = nb >> 3, r = nb & 7, x = b & 7, j = b >> 3;        // XCD group x owns q (+1 if x < r) consecutive logical blocks
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+#endif
 }
 
 // Every lane walks the tree on its own for its own query.  Measured on MI355X (370k x 370k, DIM 3): 12.5 4-wide nodes and
@@ -568,9 +697,8 @@ __device__ __forceinline__ bool coop_search(const BvhViewT<DIM>& bv, const float
                                             uint2* __restrict__ lbq, int tid) {
     const int lane = tid & 63, wbase = tid & ~63;          // this wave's slots: lbq[row * NT + wbase + col]
     const int Lq = bv.Lq, cap = Lq * WAVE;
-    f2 p2[DIM];
-#pragma unroll
-    for (int k = 0; k < DIM; k++) { p2[k].x = q[k]; p2[k].y = q[k]; }
+    QueryPt<DIM> qp;
+    make_query<DIM>(bv, q, qp);
     const float thr = fminf(best * 1.00002f, FLT_MAX);
     float minlb = FLT_MAX;
     unsigned int* slot = (unsigned int*)lbq;               // entry e of buffer b: slot[2 * ((e >> 6) * NT + wbase + (e & 63)) + b]
@@ -583,7 +711,7 @@ __device__ __forceinline__ bool coop_search(const BvhViewT<DIM>& bv, const float
             const bool act = e < n;
             const unsigned int node = act ? slot[2 * ((e >> 6) * NT + wbase + (e & 63)) + cur] : 0u;
             f2 l01, l23;
-            quad_lb<DIM>(bv.qnodes + ((0x55555555u & ((1u << (2 * L)) - 1u)) + node), p2, l01, l23);
+            quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * L)) - 1u)) + node, qp, l01, l23);
             const bool s0 = act && !(l01.x > thr), s1 = act && !(l01.y > thr), s2 = act && !(l23.x > thr), s3 = act && !(l23.y > thr);
             if (act) minlb = fminf(minlb, fminf(fminf(s0 ? FLT_MAX : l01.x, s1 ? FLT_MAX : l01.y), fminf(s2 ? FLT_MAX : l23.x, s3 ? FLT_MAX : l23.y)));
             const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1), m2 = __ballot(s2), m3 = __ballot(s3);
@@ -607,7 +735,7 @@ __device__ __forceinline__ bool coop_search(const BvhViewT<DIM>& bv, const float
         const int e = base + lane;
         if (e < n) {
             const int leaf = (int)slot[2 * ((e >> 6) * NT + wbase + (e & 63)) + cur];
-            leaf_eval<DIM>(bv.leaves + leaf, leaf, p2, b, i, ps, b2);
+            leaf_eval<DIM>(bv.leaves + leaf, leaf, qp.p2, b, i, ps, b2);
         }
     }
     const float wb = wave_min_f32(b);
@@ -626,9 +754,8 @@ __device__ __forceinline__ bool coop_search(const BvhViewT<DIM>& bv, const float
 // target other than the winner.  NT = threads of the block (layout of the LDS stacks).
 template <int DIM, int NT>
 __device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* p, float& best, int& bi, int& bpos, uint2* __restrict__ lbq, int tid) {
-    f2 p2[DIM];
-#pragma unroll
-    for (int q = 0; q < DIM; q++) { p2[q].x = p[q]; p2[q].y = p[q]; }
+    QueryPt<DIM> qp;
+    make_query<DIM>(bv, p, qp);
     float best2 = FLT_MAX, minlb = FLT_MAX;
     unsigned int touched = 0u;
     if (ICP_SEED_DESCENT && bpos < 0 && bv.Lq > 0) {
@@ -638,17 +765,17 @@ __device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* 
         int idx = 0;
         for (int L = 0; L < bv.Lq; L++) {
             f2 l01, l23;
-            quad_lb<DIM>(bv.qnodes + ((0x55555555u & ((1u << (2 * L)) - 1u)) + (unsigned int)idx), p2, l01, l23);
+            quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * L)) - 1u)) + (unsigned int)idx, qp, l01, l23);
             const float m = fminf(fminf(l01.x, l01.y), fminf(l23.x, l23.y));
             const int c = (l01.x == m) ? 0 : (l01.y == m) ? 1 : (l23.x == m) ? 2 : 3;
             idx = (idx << 2) | c;
         }
         float unused = FLT_MAX;
-        leaf_eval<DIM>(bv.leaves + idx, idx, p2, best, bi, bpos, unused);      // (the walk re-evaluates this leaf: the bound bookkeeping stays in one place)
+        leaf_eval<DIM>(bv.leaves + idx, idx, qp.p2, best, bi, bpos, unused);      // (the walk re-evaluates this leaf: the bound bookkeeping stays in one place)
     }
     if (ICP_PREFETCH_PATH && bpos >= 0) touched = quad_prefetch_path<DIM>(bv, bpos >> 3);
     QuadState st; st.L = 0; st.idx = 0; st.pending = 0ull; st.alive = true;
-    quad_run<DIM>(bv, p2, st, best, bi, bpos, best2, minlb, lbq, tid, NT);
+    quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, minlb, lbq, tid, NT);
     asm volatile("" ::"v"(touched));
     return sqrtf(fminf(best2, minlb)) * 0.999999f;
 }

@@ -1,5 +1,5 @@
-// dev_fused.hpp -- the fused matcher k_knn_bvh_post: exact BVH 1-NN + weight / reject / accumulate + (optionally) the reduction of
-// the block partials, the linear solve and the pose update, all in ONE launch per ICP iteration.
+// dev_fused.hpp -- the fused matcher k_knn_bvh_post: exact BVH 1-NN + weight / reject / accumulate in ONE launch per ICP iteration
+// (the block partials go to k_reduce_solve).
 // Part of icp_device.hpp (included from there, inside namespace icpdev); see that file for the build contract.
 // ------------------------------------------------------------------------------------------------
 // BVH k-NN with the post stage as its epilogue: the lane that found the neighbour of query k immediately weighs / rejects /
@@ -25,45 +25,13 @@ struct P2pGen {                                           // values 0..21 = sum 
         return valid ? v : 0.0;
     }
 };
-// Reduction of the block partials + solve INSIDE the matcher's launch (no k_reduce_solve launch, no second kernel boundary per
-// iteration).  Two levels of "last arriver folds": the blocks of a group of FUSE_GROUP consecutive logical blocks publish their 34
-// sums and take a ticket; the block that takes the group's last ticket adds the group's partials in block order, publishes the
-// group sums and takes a ticket of the second level; the last of those adds the group sums in group order -- fixed orders, so
-// the totals do not depend on who arrives when -- and runs the solve (solve_tail) for the whole launch.
-// Cross-workgroup visibility on this multi-XCD part (MI355X_MICROARCH.md, "Valid forms"): every published byte is stored with an
-// agent-scope atomic store (write-through, sc1), the storing wave drains its stores (s_waitcnt vmcnt(0)) before ONE of its lanes
-// adds to the ticket counter (agent-scope atomic), and every load of published bytes is an agent-scope atomic load (sc1) issued
-// after the add has returned.  No release / acquire fence: a fence would write back or invalidate a whole L2 per block, which is
-// what made the first attempt at this (round 1: __threadfence() per block) 2.5 x slower than the two-kernel form.
-constexpr int FUSE_GROUP = 64;
-// Register budget of the fused matcher: the tree walk + epilogue fit 80 VGPRs (6 waves per SIMD for DIM 3; the 6-D walk needs 106:
-// 4 waves).  The solve code at the end of the kernel runs in ONE block per launch and may spill under this cap; the walk does not.
-template <int DIM> struct FusedWaves { static constexpr int v = DIM == 3 ? 6 : 4; };
-#define FUSED_WAVES_PER_SIMD FusedWaves<DIM>::v
-struct FuseTail {
-    int enabled;                 // 0: block partials in k_reduce_solve's layout, nothing else
-    double* block_partials;      // [gridDim.x][NSUM_USED] by logical block
-    double* group_partials;      // [ceil(gridDim.x / FUSE_GROUP)][NSUM_USED]
-    unsigned int* tickets;       // [0] second level, [1 + g] group g; all zero between launches (the last arriver resets them)
-    SolveParams sp;
-};
-__device__ __forceinline__ double ld_pub(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_pub(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// sum of `count` published rows (stride NSUM_USED doubles) in row order, eight loads in flight at a time
-__device__ __forceinline__ double fold_pub(const double* src, int count) {
-    double acc = 0.0;
-    for (int b0 = 0; b0 < count; b0 += 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = (b0 + u < count) ? ld_pub(src + (size_t)(b0 + u) * NSUM_USED) : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; u++) if (b0 + u < count) acc += v[u];
-    }
-    return acc;
-}
-
+// Measured and NOT adopted (round 2): folding the block partials and solving INSIDE this launch (two levels of "last arriver
+// folds", write-through hand-over without fences).  Correct (the whole GPU suite passed with it) but slower: every level is three
+// dependent trips to memory (publish, ticket, fold) at ~1.5 us each, the tail of the launch grew by ~20 us against ~12 us for the
+// separate k_reduce_solve launch (17.3 k vs 20.0 k iterations/s).  What did pay was making k_reduce_solve itself cheaper (one load
+// round, fence-free hand-over): see dev_solve.hpp.
 template <int DIM>
-__global__ __launch_bounds__(BVH_THREADS) __attribute__((amdgpu_waves_per_eu(FUSED_WAVES_PER_SIMD, FUSED_WAVES_PER_SIMD))) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp, const FuseTail ft) {
+__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {
     extern __shared__ uint2 bvh_lbq[];                    // [Lq][BVH_THREADS] pending-sibling bounds; reused by the reduction
     constexpr int NW = BVH_THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -184,38 +152,6 @@ __global__ __launch_bounds__(BVH_THREADS) __attribute__((amdgpu_waves_per_eu(FUS
             const int nv = pp.metric == ICP_METRIC_POINT_TO_PLANE ? 27 : 22;
             if (v >= 0 && v < nv) { for (int ww = 0; ww < NW; ww++) out += lds[ww * 32 + v]; }
         }
-        if (ft.enabled) st_pub(ft.block_partials + (size_t)lb * NSUM_USED + tid, out);
-        else pp.partials[(size_t)tid * nb + lb] = out;
+        pp.partials[(size_t)tid * nb + lb] = out;
     }
-    if (!ft.enabled) return;
-    __shared__ double s_tot[NSUM];
-    __shared__ int s_final;
-    if (w == 0) {                                         // threads 0..33 live in wave 0: the whole hand-over is this wave's business
-        const int g = lb / FUSE_GROUP, ng = (nb + FUSE_GROUP - 1) / FUSE_GROUP;
-        const int gcount = min(FUSE_GROUP, nb - g * FUSE_GROUP);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned int t = 0u;
-        if (tid == 0) t = __hip_atomic_fetch_add(ft.tickets + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
-        int fin = 0;
-        if (t == (unsigned int)(gcount - 1)) {            // last block of the group (wave-uniform)
-            if (tid < NSUM_USED) st_pub(ft.group_partials + (size_t)g * NSUM_USED + tid, fold_pub(ft.block_partials + (size_t)g * FUSE_GROUP * NSUM_USED + tid, gcount));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned int t2 = 0u;
-            if (tid == 0) {
-                __hip_atomic_store(ft.tickets + 1 + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // ready for the next launch
-                t2 = __hip_atomic_fetch_add(ft.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            t2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)t2);
-            if (t2 == (unsigned int)(ng - 1)) {           // last group: the totals, then the solve
-                const double tot_a = tid < NSUM_USED ? fold_pub(ft.group_partials + tid, ng) : 0.0;
-                if (tid < NSUM) s_tot[tid] = tot_a;
-                if (tid == 0) __hip_atomic_store(ft.tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                fin = 1;
-            }
-        }
-        if (tid == 0) s_final = fin;
-    }
-    __syncthreads();
-    if (s_final) solve_tail<false>(ft.sp, s_tot);         // the symmetric metric never takes this path (it needs the means first)
 }

@@ -419,6 +419,7 @@ __device__ __forceinline__ void solve_tail(const SolveParams& sp, const double* 
 // then the waves in order) -- identical on every run and independent of block scheduling.  The block that finishes last (ticket
 // counter, release/acquire fences at agent scope) gathers the NSUM totals and runs the small fp64 solve + pose composition.
 constexpr int SOLVE_THREADS = 256;
+constexpr int SOLVE_INFLIGHT = 12;                        // loads in flight per thread: 12 x 256 = 3072 partials in ONE memory round trip
 __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParams sp) {
     __shared__ double tot[NSUM];
     __shared__ double wsum[SOLVE_THREADS / WAVE];
@@ -426,15 +427,17 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, a = blockIdx.x;
     {
         const double* __restrict__ row = sp.partials + (size_t)a * sp.nblocks;
-        // four independent running sums per thread (fixed assignment): the loads of one round are in flight together
-        double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0;
-        int b = threadIdx.x;
-        for (; b + 3 * SOLVE_THREADS < sp.nblocks; b += 4 * SOLVE_THREADS) {
-            const double v0 = row[b], v1 = row[b + SOLVE_THREADS], v2 = row[b + 2 * SOLVE_THREADS], v3 = row[b + 3 * SOLVE_THREADS];
-            x0 += v0; x1 += v1; x2 += v2; x3 += v3;
+        // The partials come from the producer kernel's write-back: every load is a trip to memory, and what this kernel costs is the
+        // number of DEPENDENT trips.  All of a thread's loads are issued before the first add (fixed assignment b = t + 256 j, added in
+        // the order of j: the same sum on every run); 2 895 partials are one round, not three.
+        double x = 0.0;
+        for (int b0 = 0; b0 < sp.nblocks; b0 += SOLVE_INFLIGHT * SOLVE_THREADS) {
+            double v[SOLVE_INFLIGHT];
+#pragma unroll
+            for (int j = 0; j < SOLVE_INFLIGHT; j++) { const int b = b0 + j * SOLVE_THREADS + (int)threadIdx.x; v[j] = b < sp.nblocks ? row[b] : 0.0; }
+#pragma unroll
+            for (int j = 0; j < SOLVE_INFLIGHT; j++) { const int b = b0 + j * SOLVE_THREADS + (int)threadIdx.x; if (b < sp.nblocks) x += v[j]; }
         }
-        for (; b < sp.nblocks; b += SOLVE_THREADS) x0 += row[b];
-        double x = (x0 + x1) + (x2 + x3);
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, WAVE);
         if (lane == 0) wsum[w] = x;
     }
@@ -442,14 +445,16 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
     if (threadIdx.x == 0) {
         double x = wsum[0];
         for (int k = 1; k < SOLVE_THREADS / WAVE; k++) x += wsum[k];
+        // hand-over without fences (MI355X_MICROARCH.md, valid forms): write-through store of the total, drained, then the ticket; the
+        // last arriver reads the totals with sc1 loads issued after its add has returned.  A release / acquire fence pair here is an L2
+        // write-back plus an L1 invalidate per block, ~3 us of this kernel's ~9.
         __hip_atomic_store(sp.totals + a, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        const unsigned t = atomicAdd(sp.ticket, 1u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(sp.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = (t == (unsigned)(NSUM_USED - 1));
     }
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
     if (threadIdx.x < NSUM) tot[threadIdx.x] = threadIdx.x < NSUM_USED ? __hip_atomic_load(sp.totals + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;   // rows NSUM_USED.. are padding
     __syncthreads();
     if (threadIdx.x == 0) *sp.ticket = 0u;                // ready for the next launch on this stream

@@ -51,7 +51,7 @@ struct Level { DevBuf idx; DevBuf order; DevBuf sorted_idx; Cloud sorted; bool s
 struct Bvh {
     bool valid = false;
     int n_valid = 0, n_leaves = 0, Lp = 1;
-    DevBuf keys, keys2, vals, vals2, temp, leaves, recs, nodes, qnodes, lvl, wbox;
+    DevBuf keys, keys2, vals, vals2, temp, leaves, recs, nodes, qnodes, qq, grid, lvl, wbox;
     const Cloud* attrs = nullptr;                     // cloud whose normals / colours go into the records (nullptr: none)
     int Lq = 0;                                       // 4-wide levels
     std::vector<int> finite_idx;                     // indices of the finite target points, increasing
@@ -70,7 +70,6 @@ struct icp_ctx {
     bool block_levels = true;            // BVH build: levels with slices <= 2048 points in one LDS kernel (ICP_HIP_BLOCK_LEVELS=0: global sorts)
     bool trace = false;                  // ICP_HIP_TRACE=1: per-iteration stage times on stderr
     bool fuse_post = true;               // BVH matcher runs weight / reject / accumulate as its epilogue (ICP_HIP_FUSE_POST=0 disables)
-    bool fuse_solve = true;              // ... and the reduction of the block partials + the solve inside the same launch (ICP_HIP_FUSE_SOLVE=0: k_reduce_solve)
     icp_params prm;
     Cloud tgt, src, qry;                 // qry: scratch cloud of icp_query_matches
     Cloud nrm_cloud; Bvh nrm_bvh;        // scratch of icp_estimate_normals
@@ -81,7 +80,7 @@ struct icp_ctx {
     std::map<int, Level> levels;         // multires selections by decimation factor
     DevBuf sel_lists, sel_counts, sel_blocks;            // RANDOM_SAMPLING: per-iteration index lists, their sizes, scan scratch
     DevBuf qstate;                                       // incremental k-NN: per-query position + bound on the other targets
-    DevBuf ps, matches, d2, best64, nn_raw, partials, gpartials, tickets, totals, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
+    DevBuf ps, matches, d2, best64, nn_raw, partials, totals, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
     Cloud conv_src, conv_ref; int conv_n = 0;
     float cos_reject = 0.5f;
     std::vector<hipEvent_t> events;
@@ -295,6 +294,14 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
         const long long nq = ((1ll << (2 * b.Lq)) - 1) / 3;
         if ((rc = ensure(c, b.qnodes, (size_t)(nq > 0 ? nq : 1) * sizeof(BvhQuadT<DIM>)))) return rc;
         if (nq > 0) hipLaunchKernelGGL(k_bvh_quad_nodes<DIM>, dim3((unsigned)((nq * 4 + 255) / 256)), dim3(256), 0, c->stream, b.nodes.as<BvhNodeT<DIM>>(), pad, b.Lq, b.qnodes.as<BvhQuadT<DIM>>());
+#if ICP_QUANT_NODES
+        if ((rc = ensure(c, b.qq, (size_t)(nq > 0 ? nq : 1) * sizeof(BvhQuadQT<DIM>)))) return rc;
+        if ((rc = ensure(c, b.grid, sizeof(BvhGrid)))) return rc;
+        if (nq > 0) {
+            hipLaunchKernelGGL(k_bvh_grid<DIM>, dim3(1), dim3(64), 0, c->stream, b.nodes.as<BvhNodeT<DIM>>(), b.grid.as<BvhGrid>());
+            hipLaunchKernelGGL(k_bvh_quantize<DIM>, dim3((unsigned)((nq * 4 + 255) / 256)), dim3(256), 0, c->stream, b.qnodes.as<BvhQuadT<DIM>>(), (int)nq, b.grid.as<BvhGrid>(), b.qq.as<BvhQuadQT<DIM>>());
+        }
+#endif
     }
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipEventRecord(e1, c->stream));
@@ -324,18 +331,14 @@ PostParams make_post_params(icp_ctx* c, const Cloud& src, const int* sel, int n)
     return pp;
 }
 
-// What the loop wants solved inside the matcher's launch (fused reduction + solve): the record slot of this iteration.
-struct SolveRequest { icp_iter_stats* d_stats; int update_pose; bool done; };
-
 // fuse != nullptr: run the post stage (weight / reject / accumulate) as the epilogue of the search; *fused_blocks receives the
-// number of block partials written.  sr != nullptr (and the context allows it): the reduction of those partials, the solve and the
-// pose update run in the same launch too (sr->done = true) -- nothing is left for launch_post_and_solve.
+// number of block partials written.
 template <int DIM>
-int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnParams& kp, const int* order, int n, const Cloud* fuse, int* fused_blocks, SolveRequest* sr) {
+int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnParams& kp, const int* order, int n, const Cloud* fuse, int* fused_blocks) {
     int rc;
     if (!b.valid && (rc = build_bvh<DIM>(c, b, cp))) return rc;
     BvhViewT<DIM> bv; bv.leaves = b.leaves.as<BvhLeafT<DIM>>(); bv.nodes = b.nodes.as<BvhNodeT<DIM>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
-    bv.qnodes = b.qnodes.as<BvhQuadT<DIM>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>();
+    bv.qnodes = b.qnodes.as<BvhQuadT<DIM>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>(); bv.qq = b.qq.as<BvhQuadQT<DIM>>(); bv.grid = b.grid.as<BvhGrid>();
     const int nb = (n + BVH_THREADS - 1) / BVH_THREADS;
     const size_t stack_bytes = (size_t)(b.Lq > 0 ? b.Lq : 1) * BVH_THREADS * 8;
     if (fuse) {
@@ -343,21 +346,8 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
         PostParams pp = make_post_params(c, *fuse, kp.sel, n);
         pp.matches = nullptr;                                                     // the loop never reads the records of a fused iteration
         KnnParams kf = kp; kf.d2_out = nullptr; kf.out = nullptr;                 // ... nor the distances
-        FuseTail ft; memset(&ft, 0, sizeof(ft));
-        if (sr && c->fuse_solve) {
-            const int ng = (nb + FUSE_GROUP - 1) / FUSE_GROUP;
-            if ((rc = ensure(c, c->gpartials, (size_t)ng * NSUM_USED * 8))) return rc;
-            if ((size_t)(ng + 1) * 4 > c->tickets.cap || !c->tickets.p) {
-                if ((rc = ensure(c, c->tickets, (size_t)(ng + 1) * 4 + 1024))) return rc;
-                HIPCK(c, hipMemsetAsync(c->tickets.p, 0, c->tickets.cap, c->stream));      // every launch leaves them zero again
-            }
-            ft.enabled = 1; ft.block_partials = c->partials.as<double>(); ft.group_partials = c->gpartials.as<double>(); ft.tickets = c->tickets.as<unsigned int>();
-            ft.sp.ps = c->ps.as<PoseState>(); ft.sp.metric = c->prm.metric; ft.sp.phase = 0; ft.sp.stats = sr->d_stats; ft.sp.n_src = n;
-            ft.sp.update_pose = sr->update_pose; ft.sp.sums_out = nullptr;
-            sr->done = true;
-        }
         const size_t red_bytes = (size_t)(BVH_THREADS / WAVE) * 33 * 8;           // the reduction reuses the (dead) traversal stacks
-        hipLaunchKernelGGL(k_knn_bvh_post<DIM>, dim3(nb), dim3(BVH_THREADS), stack_bytes > red_bytes ? stack_bytes : red_bytes, c->stream, kf, bv, order, pp, ft);
+        hipLaunchKernelGGL(k_knn_bvh_post<DIM>, dim3(nb), dim3(BVH_THREADS), stack_bytes > red_bytes ? stack_bytes : red_bytes, c->stream, kf, bv, order, pp);
         *fused_blocks = nb;
     } else {
         hipLaunchKernelGGL(k_knn_bvh<DIM>, dim3(nb), dim3(BVH_THREADS), stack_bytes, c->stream, kp, bv, order);
@@ -368,7 +358,7 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
 
 // Enqueue the matching stage (no sync).  fused_blocks != nullptr allows the BVH matcher to run the post stage as its epilogue;
 // it is set to the number of block partials written, or left 0 when the matcher in use does not fuse.
-int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr, SolveRequest* sr = nullptr) {
+int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr) {
     const icp_params& p = c->prm;
     int rc;
     if (fused_blocks) *fused_blocks = 0;
@@ -401,8 +391,8 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr, Sol
             kp.qstate = c->qstate.as<float4>(); kp.incremental = 1;
         }
         const Cloud* fuse = (fused_blocks != nullptr && p.metric != ICP_METRIC_SYMMETRIC && !q.pretransformed) ? q.cl : nullptr;
-        if (q.use_colors) return launch_bvh_query<6>(c, c->bvh6, target_coords6(c), kp, q.order, q.n, fuse, fused_blocks, fuse ? sr : nullptr);
-        return launch_bvh_query<3>(c, c->bvh, target_coords3(c), kp, q.order, q.n, fuse, fused_blocks, fuse ? sr : nullptr);
+        if (q.use_colors) return launch_bvh_query<6>(c, c->bvh6, target_coords6(c), kp, q.order, q.n, fuse, fused_blocks);
+        return launch_bvh_query<3>(c, c->bvh, target_coords3(c), kp, q.order, q.n, fuse, fused_blocks);
     }
     const int bx = (q.n + WAVE - 1) / WAVE;
     const int nch = kp.mpad / KNN_CH;
@@ -552,7 +542,7 @@ int ensure_events(icp_ctx* c, size_t count) {
 
 extern "C" {
 
-const char* icp_version(void) { return "icp_hip gfx950 r1"; }
+const char* icp_version(void) { return ICP_QUANT_NODES ? "icp_hip gfx950 r2 (quantised nodes)" : "icp_hip gfx950 r2"; }
 
 uint32_t icp_select_hash(uint32_t seed, uint32_t iteration, uint32_t index) { return select_hash(seed, iteration, index); }
 
@@ -579,7 +569,6 @@ int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out) {
     memset(&c->timing, 0, sizeof(c->timing));
     if (hipSetDevice(device) != hipSuccess) { delete c; return ICP_ERR_HIP; }
     { const char* e = getenv("ICP_HIP_FUSE_POST"); if (e && e[0] == '0') c->fuse_post = false; }
-    { const char* e = getenv("ICP_HIP_FUSE_SOLVE"); if (e && e[0] == '0') c->fuse_solve = false; }
     { const char* e = getenv("ICP_HIP_BLOCK_LEVELS"); if (e && e[0] == '0') c->block_levels = false; }
     { const char* e = getenv("ICP_HIP_TRACE"); if (e && e[0] == '1') c->trace = true; }
     { const char* e = getenv("ICP_HIP_STAGE_EVENTS"); if (e && e[0] >= '0' && e[0] <= '9') c->stage_timing = atoi(e); }
@@ -604,11 +593,11 @@ int icp_ctx_destroy(icp_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release(c->tgt); release(c->src); release(c->qry); release(c->conv_src); release(c->conv_ref);
     release(c->nrm_cloud);
-    for (Bvh* b : {&c->bvh, &c->bvh6, &c->nrm_bvh}) { release(b->qnodes); release(b->recs); }
+    for (Bvh* b : {&c->bvh, &c->bvh6, &c->nrm_bvh}) { release(b->qnodes); release(b->recs); release(b->qq); release(b->grid); }
     for (Bvh* b : {&c->bvh6, &c->nrm_bvh}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
     release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) release(kv.second);
-    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->gpartials); release(c->tickets); release(c->totals); release(c->sums);
+    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
@@ -841,11 +830,10 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
             const bool seed = i > 0 && factors[i] == factors[i - 1] && ns[i - 1] > 0 && p.selection == 0;
             QuerySet q{clouds[i], sels[i], ns[i], 0, p.color_icp != 0 && p.matching == ICP_MATCH_KNN, seed, orders[i]};
             int fused = 0;
-            SolveRequest sr{d_st, 1, false};
-            if ((rc = launch_match(c, q, c->fuse_post ? &fused : nullptr, &sr))) return rc;
+            if ((rc = launch_match(c, q, c->fuse_post ? &fused : nullptr))) return rc;
             if (ev) HIPCK(c, hipEventRecord(E(i, 1), c->stream));
-            // fused epilogue: there is no separate post stage to bracket; fused solve: nothing left to launch at all
-            if (!sr.done && (rc = launch_post_and_solve(c, *clouds[i], sels[i], ns[i], d_st, nullptr, 1, (ev && !fused) ? E(i, 2) : nullptr, fused))) return rc;
+            // fused epilogue: there is no separate post stage to bracket
+            if ((rc = launch_post_and_solve(c, *clouds[i], sels[i], ns[i], d_st, nullptr, 1, (ev && !fused) ? E(i, 2) : nullptr, fused))) return rc;
             post_event[i] = ev && !fused;
         } else if (ev) {
             HIPCK(c, hipEventRecord(E(i, 1), c->stream));
@@ -1037,7 +1025,7 @@ int icp_estimate_normals(icp_ctx* c, const float* xyz, int32_t n, int32_t k, con
     CoordPtrs<3> cp; cp.c[0] = cl.x.as<float>(); cp.c[1] = cl.y.as<float>(); cp.c[2] = cl.z.as<float>();
     if ((rc = build_bvh<3>(c, b, cp))) return rc;
     BvhViewT<3> bv; bv.leaves = b.leaves.as<BvhLeafT<3>>(); bv.nodes = b.nodes.as<BvhNodeT<3>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
-    bv.qnodes = b.qnodes.as<BvhQuadT<3>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>();
+    bv.qnodes = b.qnodes.as<BvhQuadT<3>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>(); bv.qq = b.qq.as<BvhQuadQT<3>>(); bv.grid = b.grid.as<BvhGrid>();
     int depth = 0; while ((1 << depth) < b.Lp) depth++;
     if ((rc = ensure(c, c->staging, (size_t)n * 16))) return rc;
     float* d_n = c->staging.as<float>(); float* d_c = d_n + (size_t)n * 3;

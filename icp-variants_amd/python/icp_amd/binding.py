@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.abspath(os.path.join(_HERE, "..", ".."))            # icp-variants_amd/
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libicp_hip.so")
+LIB_PATH = os.environ.get("ICP_HIP_LIB") or os.path.join(PKG_ROOT, "lib", "libicp_hip.so")     # ICP_HIP_LIB: development A/B builds
 
 MATCH_DTYPE = np.dtype([("idx", np.int32), ("weight", np.float32)])
 
