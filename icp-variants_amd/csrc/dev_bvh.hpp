@@ -574,6 +574,25 @@ __device__ __forceinline__ unsigned int quad_prefetch_path(const BvhViewT<DIM>& 
     return sink;
 }
 
+#ifndef ICP_BITS_STACK
+#define ICP_BITS_STACK 0
+#endif
+// ICP_BITS_STACK: the pending siblings are remembered as BITS only (4 per level, one 64-bit register), not with their bounds.
+// A seeded walk is in effect a range query -- its prune threshold is almost final from the first step on -- so re-testing a parked
+// sibling against the improved threshold when it is popped (what the 16-bit bounds in LDS are for) buys next to nothing, while the
+// packing, the LDS round trip and the unpack / min / select of every pop are a third of the walk's instructions.  With bits only a
+// pop is "highest level with a bit set, lowest bit": no loop, no LDS.  A sibling that went stale is noticed one node later (its own
+// children all fail the test), which only costs that node; exactness is untouched (a box is still skipped only on lb > thr, and
+// every skipped box enters minlb when it is tested).
+__device__ __forceinline__ void quad_pop_bits(QuadState& st) {
+    if (!st.alive && st.pending) {
+        const int lv = (63 - __clzll((long long)st.pending)) >> 2;                // deepest level with pending children
+        const unsigned int bits = (unsigned int)(st.pending >> (4 * lv)) & 0xFu;
+        const int c = __ffs((int)bits) - 1;
+        st.pending &= ~(1ull << (4 * lv + c));
+        st.idx = ((st.idx >> (2 * (st.L - lv))) << 2) | c; st.L = lv + 1; st.alive = true;
+    }
+}
 template <int DIM>
 __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<DIM>& qp, QuadState& st,
                                          float& best, int& bi, int& bpos, float& best2, float& minlb, uint2* __restrict__ lbq, int tid, int nthreads) {
@@ -591,6 +610,9 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<
             if (!(m > thr)) {
                 const int c = (l01.x == m) ? 0 : (l01.y == m) ? 1 : (l23.x == m) ? 2 : 3;
                 const unsigned int pend = ((s0 ? 1u : 0u) | (s1 ? 2u : 0u) | (s2 ? 4u : 0u) | (s3 ? 8u : 0u)) & ~(1u << c);
+#if ICP_BITS_STACK
+                st.pending |= (unsigned long long)pend << (4 * st.L);
+#else
                 if (pend) {
                     uint2 w;
                     w.x = (__float_as_uint(l01.x) >> 16) | (__float_as_uint(l01.y) & 0xFFFF0000u);
@@ -598,15 +620,24 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<
                     lbq[st.L * nthreads + tid] = w;
                     st.pending |= (unsigned long long)pend << (4 * st.L);
                 }
+#endif
                 st.idx = (st.idx << 2) | c; st.L++;
             } else st.alive = false;                      // all four children pruned
+#if ICP_BITS_STACK
+            quad_pop_bits(st);
+#else
             quad_pop(st, lbq, tid, nthreads, thr, minlb);
+#endif
         }
         if (st.alive) {
             leaf_eval<DIM>(bv.leaves + st.idx, st.idx, qp.p2, best, bi, bpos, best2);
             thr = fminf(best * 1.00002f, FLT_MAX);
             st.alive = false;
+#if ICP_BITS_STACK
+            quad_pop_bits(st);
+#else
             quad_pop(st, lbq, tid, nthreads, thr, minlb);
+#endif
         }
     }
 }

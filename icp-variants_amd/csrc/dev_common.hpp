@@ -66,3 +66,51 @@ __global__ void k_fill_u64(unsigned long long* p, int n, unsigned long long v) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Set-up passes over a freshly uploaded cloud, on the device (round 1 looped over every point on the host for these):
+//   k_mark_finite : flag[i] = point i finite (&& normal finite, when normals are given)  -- the finite filter of the index build
+//                   (non-finite targets can never win the argmin) and PointCloud::getCoarseResolution's validity test (PointCloud.h:334)
+//   k_bbox        : bounding box of the finite points as ordered-bit unsigned min / max (one atomic per block and bound)
+//   k_stride_flags: flag of every `factor`-th point, for the multi-resolution selections
+__global__ void k_mark_finite(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                              const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ nz, int n, uint8_t* __restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool ok = finite3(x[i], y[i], z[i]);
+    if (ok && nx) ok = finite3(nx[i], ny[i], nz[i]);
+    flag[i] = ok ? 1 : 0;
+}
+__device__ __forceinline__ unsigned int ordered_bits_u(float f) { const unsigned int u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float from_ordered_bits_u(unsigned int u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+__global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, int n, unsigned int* __restrict__ box /* [6]: min xyz, max xyz; preset to ~0 / 0 */) {
+    __shared__ unsigned int sm[4][6];
+    unsigned int lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float a = x[i], b = y[i], c = z[i];
+        if (finite3(a, b, c)) {
+            const unsigned int o[3] = {ordered_bits_u(a), ordered_bits_u(b), ordered_bits_u(c)};
+#pragma unroll
+            for (int k = 0; k < 3; k++) { lo[k] = min(lo[k], o[k]); hi[k] = max(hi[k], o[k]); }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lo[k] = min(lo[k], (unsigned int)__shfl_down((int)lo[k], off, WAVE)); hi[k] = max(hi[k], (unsigned int)__shfl_down((int)hi[k], off, WAVE)); }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { for (int k = 0; k < 3; k++) { sm[w][k] = lo[k]; sm[w][3 + k] = hi[k]; } }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        unsigned int v = sm[0][k];
+        for (int ww = 1; ww < 4; ww++) v = k < 3 ? min(v, sm[ww][k]) : max(v, sm[ww][k]);
+        if (k < 3) atomicMin(box + k, v); else atomicMax(box + k, v);
+    }
+}
+__global__ void k_stride_flags(const uint8_t* __restrict__ flag, int n, int factor, int count, uint8_t* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < count) out[j] = flag[(size_t)j * factor];
+}
+struct MulBy { int f; __host__ __device__ int operator()(int j) const { return j * f; } };

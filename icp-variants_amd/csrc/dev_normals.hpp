@@ -105,14 +105,21 @@ __global__ void k_iota(int* p, int n) { const int i = blockIdx.x * blockDim.x + 
 
 // Morton key of the (untransformed) query points -> spatially coherent waves for k_knn_bvh.
 __global__ void k_query_keys(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z, const int* __restrict__ sel, int n,
-                             float lox, float loy, float loz, float sx, float sy, float sz, unsigned long long* __restrict__ keys, int* __restrict__ vals) {
+                             const unsigned int* __restrict__ box /* k_bbox of the cloud */, unsigned long long* __restrict__ keys, int* __restrict__ vals) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const int i = sel ? sel[t] : t;
     const float a = x[i], b = y[i], c = z[i];
     unsigned long long key = ~0ull;
     if (finite3(a, b, c)) {
-        const float fa = fminf(fmaxf((a - lox) * sx, 0.f), 2097151.f), fb = fminf(fmaxf((b - loy) * sy, 0.f), 2097151.f), fc = fminf(fmaxf((c - loz) * sz, 0.f), 2097151.f);
+        float lo[3], sc[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            lo[k] = from_ordered_bits_u(box[k]);
+            const float ext = from_ordered_bits_u(box[3 + k]) - lo[k];
+            sc[k] = (ext > 0.f && isfinite(ext)) ? 2097151.f / ext : 0.f;
+        }
+        const float fa = fminf(fmaxf((a - lo[0]) * sc[0], 0.f), 2097151.f), fb = fminf(fmaxf((b - lo[1]) * sc[1], 0.f), 2097151.f), fc = fminf(fmaxf((c - lo[2]) * sc[2], 0.f), 2097151.f);
         key = spread21((unsigned int)fa) | (spread21((unsigned int)fb) << 1) | (spread21((unsigned int)fc) << 2);
     }
     keys[t] = key; vals[t] = t;

@@ -10,6 +10,9 @@
 #include <cmath>
 #include "icp_device.hpp"
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -54,7 +57,7 @@ struct Bvh {
     DevBuf keys, keys2, vals, vals2, temp, leaves, recs, nodes, qnodes, qq, grid, lvl, wbox;
     const Cloud* attrs = nullptr;                     // cloud whose normals / colours go into the records (nullptr: none)
     int Lq = 0;                                       // 4-wide levels
-    std::vector<int> finite_idx;                     // indices of the finite target points, increasing
+    const int* d_finite = nullptr;                    // device list of the finite points' indices, increasing (owned by the context)
     double build_ms = 0.0;
 };
 
@@ -74,8 +77,9 @@ struct icp_ctx {
     Cloud tgt, src, qry;                 // qry: scratch cloud of icp_query_matches
     Cloud nrm_cloud; Bvh nrm_bvh;        // scratch of icp_estimate_normals
     Bvh bvh, bvh6;                       // exact kd-ordered BVH of the target over xyz / over xyz+rgb (knn_backend == ICP_KNN_LBVH)
-    std::vector<uint8_t> src_valid;      // host mask: finite point && finite normal (PointCloud.h:334)
-    float src_lo[3] = {0, 0, 0}, src_hi[3] = {0, 0, 0};   // bounding box of the finite source points
+    DevBuf src_flag, src_box;            // per source point: finite point && finite normal (PointCloud.h:334); bounding box of the finite points (ordered bits)
+    DevBuf tgt_flag, tgt_finite, nrm_finite, sel_temp, d_count;   // finite filters of the index builds, compaction scratch
+    void* pin_up = nullptr; size_t pin_up_cap = 0; hipEvent_t up_ev = nullptr; bool up_pending = false;   // page-locked upload staging + "copy has left it" event
     DevBuf okeys, okeys2, ovals, otemp;  // scratch of the Morton sort of the queries
     std::map<int, Level> levels;         // multires selections by decimation factor
     DevBuf sel_lists, sel_counts, sel_blocks;            // RANDOM_SAMPLING: per-iteration index lists, their sizes, scan scratch
@@ -141,45 +145,93 @@ struct DrainOnError {
     int done(int rc = ICP_OK) { ok = (rc == ICP_OK); return rc; }
 };
 
-// Host AoS -> device SoA (+ optional padding with pad_value).
-int upload3(icp_ctx* c, const float* aos, int n, int npad, float pad_value, DevBuf& x, DevBuf& y, DevBuf& z) {
-    int rc;
-    if ((rc = ensure(c, c->staging, (size_t)n * 12))) return rc;
-    if ((rc = ensure(c, x, (size_t)npad * 4))) return rc;
-    if ((rc = ensure(c, y, (size_t)npad * 4))) return rc;
-    if ((rc = ensure(c, z, (size_t)npad * 4))) return rc;
-    HIPCK(c, hipMemcpyAsync(c->staging.p, aos, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_deinterleave3, dim3((npad + 255) / 256), dim3(256), 0, c->stream, c->staging.as<float>(), n, npad, pad_value,
-                       x.as<float>(), y.as<float>(), z.as<float>());
-    HIPCK(c, hipGetLastError());
-    HIPCK(c, hipStreamSynchronize(c->stream));      // staging is reused by the next upload
+// Host clouds -> device SoA planes.  The whole cloud (points, normals, colours) goes through ONE page-locked staging buffer and
+// ONE asynchronous copy, the AoS -> SoA kernels follow on the stream, and nothing here waits for the device: the only host-side
+// wait is for the previous upload to have left the staging buffer.  (Round 1: pageable copies + one synchronisation per plane.)
+int ensure_pin_up(icp_ctx* c, size_t bytes) {
+    if (c->up_pending) { HIPCK(c, hipEventSynchronize(c->up_ev)); c->up_pending = false; }
+    if (bytes <= c->pin_up_cap && c->pin_up) return ICP_OK;
+    if (c->pin_up) { HIPCK(c, hipHostFree(c->pin_up)); c->pin_up = nullptr; c->pin_up_cap = 0; }
+    const size_t want = bytes < 65536 ? 65536 : bytes + bytes / 8;
+    HIPCK(c, hipHostMalloc(&c->pin_up, want, hipHostMallocDefault));
+    c->pin_up_cap = want;
+    if (!c->up_ev) HIPCK(c, hipEventCreateWithFlags(&c->up_ev, hipEventDisableTiming));
     return ICP_OK;
 }
-int upload_colors(icp_ctx* c, const uint8_t* rgba, int n, int npad, Cloud& cl) {
+int upload_cloud(icp_ctx* c, Cloud& cl, const float* xyz, const float* nrm, const uint8_t* rgba, int n, bool pad_inf) {
+    const int npad = pad_inf ? ((n + 63) / 64) * 64 : n;
+    const size_t b_xyz = (size_t)n * 12, b_nrm = nrm ? (size_t)n * 12 : 0, b_col = rgba ? (size_t)n * 4 : 0, total = b_xyz + b_nrm + b_col;
     int rc;
-    if ((rc = ensure(c, c->staging, (size_t)n * 4))) return rc;
-    if ((rc = ensure(c, cl.rgba, (size_t)npad * 4))) return rc;
-    if ((rc = ensure(c, cl.cr, (size_t)npad * 4))) return rc;
-    if ((rc = ensure(c, cl.cg, (size_t)npad * 4))) return rc;
-    if ((rc = ensure(c, cl.cb, (size_t)npad * 4))) return rc;
-    HIPCK(c, hipMemcpyAsync(c->staging.p, rgba, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_colors, dim3((npad + 255) / 256), dim3(256), 0, c->stream, c->staging.as<uint8_t>(), n, npad,
-                       cl.rgba.as<uint32_t>(), cl.cr.as<float>(), cl.cg.as<float>(), cl.cb.as<float>());
+    if ((rc = ensure_pin_up(c, total))) return rc;
+    if ((rc = ensure(c, c->staging, total))) return rc;
+    char* h = (char*)c->pin_up;
+    memcpy(h, xyz, b_xyz);
+    if (nrm) memcpy(h + b_xyz, nrm, b_nrm);
+    if (rgba) memcpy(h + b_xyz + b_nrm, rgba, b_col);
+    HIPCK(c, hipMemcpyAsync(c->staging.p, h, total, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipEventRecord(c->up_ev, c->stream)); c->up_pending = true;
+    const char* d = c->staging.as<char>();
+    const dim3 g((npad + 255) / 256), b(256);
+    for (DevBuf* pl : {&cl.x, &cl.y, &cl.z}) if ((rc = ensure(c, *pl, (size_t)npad * 4))) return rc;
+    hipLaunchKernelGGL(k_deinterleave3, g, b, 0, c->stream, (const float*)d, n, npad, INFINITY, cl.x.as<float>(), cl.y.as<float>(), cl.z.as<float>());
+    cl.has_normals = nrm != nullptr;
+    if (nrm) {
+        for (DevBuf* pl : {&cl.nx, &cl.ny, &cl.nz}) if ((rc = ensure(c, *pl, (size_t)n * 4))) return rc;
+        hipLaunchKernelGGL(k_deinterleave3, dim3((n + 255) / 256), b, 0, c->stream, (const float*)(d + b_xyz), n, n, 0.f, cl.nx.as<float>(), cl.ny.as<float>(), cl.nz.as<float>());
+    }
+    cl.has_colors = rgba != nullptr;
+    if (rgba) {
+        for (DevBuf* pl : {&cl.rgba, &cl.cr, &cl.cg, &cl.cb}) if ((rc = ensure(c, *pl, (size_t)npad * 4))) return rc;
+        hipLaunchKernelGGL(k_colors, g, b, 0, c->stream, (const uint8_t*)(d + b_xyz + b_nrm), n, npad, cl.rgba.as<uint32_t>(), cl.cr.as<float>(), cl.cg.as<float>(), cl.cb.as<float>());
+    }
     HIPCK(c, hipGetLastError());
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    cl.n = n; cl.npad = npad;
+    return ICP_OK;
+}
+// one plane triple through the same staging path (convergence reference)
+int upload3(icp_ctx* c, const float* aos, int n, int npad, float pad_value, DevBuf& x, DevBuf& y, DevBuf& z) {
+    int rc;
+    if ((rc = ensure_pin_up(c, (size_t)n * 12))) return rc;
+    if ((rc = ensure(c, c->staging, (size_t)n * 12))) return rc;
+    for (DevBuf* pl : {&x, &y, &z}) if ((rc = ensure(c, *pl, (size_t)npad * 4))) return rc;
+    memcpy(c->pin_up, aos, (size_t)n * 12);
+    HIPCK(c, hipMemcpyAsync(c->staging.p, c->pin_up, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipEventRecord(c->up_ev, c->stream)); c->up_pending = true;
+    hipLaunchKernelGGL(k_deinterleave3, dim3((npad + 255) / 256), dim3(256), 0, c->stream, c->staging.as<float>(), n, npad, pad_value, x.as<float>(), y.as<float>(), z.as<float>());
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipStreamSynchronize(c->stream));      // staging is reused by the caller's next plane
     return ICP_OK;
 }
 
-int upload_cloud(icp_ctx* c, Cloud& cl, const float* xyz, const float* nrm, const uint8_t* rgba, int n, bool pad_inf) {
-    const int npad = pad_inf ? ((n + 63) / 64) * 64 : n;
+// Indices j * factor (j = 0 .. count - 1) whose flag is set, in increasing order, compacted on the device (rocPRIM select); one
+// 4-byte copy returns how many there are.  flags: one byte per j.
+int compact_flagged(icp_ctx* c, const uint8_t* d_flags, int count, int factor, DevBuf& out, int* n_out) {
     int rc;
-    if ((rc = upload3(c, xyz, n, npad, INFINITY, cl.x, cl.y, cl.z))) return rc;
-    cl.has_normals = nrm != nullptr;
-    if (nrm && (rc = upload3(c, nrm, n, n, 0.f, cl.nx, cl.ny, cl.nz))) return rc;
-    cl.has_colors = rgba != nullptr;
-    if (rgba && (rc = upload_colors(c, rgba, n, npad, cl))) return rc;
-    cl.n = n; cl.npad = npad;
+    if ((rc = ensure(c, out, (size_t)(count > 0 ? count : 1) * 4))) return rc;
+    if ((rc = ensure(c, c->d_count, 16))) return rc;
+    *n_out = 0;
+    if (count <= 0) return ICP_OK;
+    auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), MulBy{factor});
+    size_t tb = 0;
+    HIPCK(c, rocprim::select(nullptr, tb, in, d_flags, out.as<int>(), c->d_count.as<int>(), (size_t)count, c->stream));
+    if ((rc = ensure(c, c->sel_temp, tb))) return rc;
+    HIPCK(c, rocprim::select(c->sel_temp.p, tb, in, d_flags, out.as<int>(), c->d_count.as<int>(), (size_t)count, c->stream));
+    if ((rc = ensure_pinned(c, 4096))) return rc;
+    int* h = (int*)((char*)c->pinned + 2048);            // (the first bytes of the pinned block stage the pose)
+    HIPCK(c, hipMemcpyAsync(h, c->d_count.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    *n_out = *h;
     return ICP_OK;
+}
+// finite filter of a cloud that is already on the device -> flag bytes + compacted index list
+int finite_list(icp_ctx* c, const Cloud& cl, bool with_normals, DevBuf& flag, DevBuf& list, int* n_out) {
+    int rc;
+    if ((rc = ensure(c, flag, (size_t)cl.n))) return rc;
+    const bool nrm = with_normals && cl.has_normals;
+    hipLaunchKernelGGL(k_mark_finite, dim3((cl.n + 255) / 256), dim3(256), 0, c->stream, cl.x.as<float>(), cl.y.as<float>(), cl.z.as<float>(),
+                       nrm ? cl.nx.as<float>() : nullptr, nrm ? cl.ny.as<float>() : nullptr, nrm ? cl.nz.as<float>() : nullptr, cl.n, flag.as<uint8_t>());
+    HIPCK(c, hipGetLastError());
+    return compact_flagged(c, flag.as<uint8_t>(), cl.n, 1, list, n_out);
 }
 
 // Upload the pose state.  Staged through the context's page-locked buffer: no synchronisation here -- every entry point
@@ -211,10 +263,8 @@ int build_query_order(icp_ctx* c, const int* d_sel, int n, DevBuf& out) {
     if ((rc = ensure(c, c->okeys2, (size_t)n * 8))) return rc;
     if ((rc = ensure(c, c->ovals, (size_t)n * 4))) return rc;
     if ((rc = ensure(c, out, (size_t)n * 4))) return rc;
-    float sc[3];
-    for (int k = 0; k < 3; k++) { const float ext = c->src_hi[k] - c->src_lo[k]; sc[k] = (ext > 0.f && std::isfinite(ext)) ? 2097151.f / ext : 0.f; }
     hipLaunchKernelGGL(k_query_keys, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->src.x.as<float>(), c->src.y.as<float>(), c->src.z.as<float>(), d_sel, n,
-                       c->src_lo[0], c->src_lo[1], c->src_lo[2], sc[0], sc[1], sc[2], c->okeys.as<unsigned long long>(), c->ovals.as<int>());
+                       c->src_box.as<unsigned int>(), c->okeys.as<unsigned long long>(), c->ovals.as<int>());
     size_t temp_bytes = 0;
     HIPCK(c, rocprim::radix_sort_pairs(nullptr, temp_bytes, c->okeys.as<unsigned long long>(), c->okeys2.as<unsigned long long>(), c->ovals.as<int>(), out.as<int>(), (size_t)n, 0, 64, c->stream));
     if ((rc = ensure(c, c->otemp, temp_bytes))) return rc;
@@ -249,8 +299,8 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
     if ((rc = ensure(c, b.wbox, (size_t)((cap + 63) / 64) * 2 * DIM * 4))) return rc;
     int* perm = b.vals.as<int>(); int* perm2 = b.vals2.as<int>();
     if (nv > 0) {
-        // finite targets in index order (host list from icp_set_target)
-        HIPCK(c, hipMemcpyAsync(perm, b.finite_idx.data(), (size_t)nv * 4, hipMemcpyHostToDevice, c->stream));
+        // finite targets in index order (device list from icp_set_target)
+        HIPCK(c, hipMemcpyAsync(perm, b.d_finite, (size_t)nv * 4, hipMemcpyDeviceToDevice, c->stream));
         size_t temp_bytes = 0;
         HIPCK(c, rocprim::radix_sort_pairs(nullptr, temp_bytes, b.keys.as<unsigned long long>(), b.keys2.as<unsigned long long>(), perm, perm2, (size_t)nv, 0, 64, c->stream));
         if ((rc = ensure(c, b.temp, temp_bytes))) return rc;
@@ -472,12 +522,11 @@ int get_level(icp_ctx* c, int factor, const int** d_idx, int* n_out, const int**
         Level lv;
         int rc;
         if (factor > 0) {
-            std::vector<int> idx;
-            idx.reserve(c->src.n / factor + 1);
-            for (int i = 0; i < c->src.n; i += factor) if (c->src_valid[i]) idx.push_back(i);
-            lv.n = (int)idx.size();
-            if ((rc = ensure(c, lv.idx, (size_t)(lv.n > 0 ? lv.n : 1) * 4))) return rc;
-            if (lv.n > 0) HIPCK(c, hipMemcpy(lv.idx.p, idx.data(), (size_t)lv.n * 4, hipMemcpyHostToDevice));
+            const int count = (c->src.n + factor - 1) / factor;              // candidates i = 0, factor, 2 factor, ... (PointCloud.h:331)
+            if ((rc = ensure(c, c->staging, (size_t)count))) return rc;
+            hipLaunchKernelGGL(k_stride_flags, dim3((count + 255) / 256), dim3(256), 0, c->stream, c->src_flag.as<uint8_t>(), c->src.n, factor, count, c->staging.as<uint8_t>());
+            HIPCK(c, hipGetLastError());
+            if ((rc = compact_flagged(c, c->staging.as<uint8_t>(), count, factor, lv.idx, &lv.n))) return rc;
         } else lv.n = c->src.n;                                   // factor 0: every point, no index list
         it = c->levels.emplace(factor, lv).first;
     }
@@ -599,6 +648,9 @@ int icp_ctx_destroy(icp_ctx* c) {
     for (auto& kv : c->levels) release(kv.second);
     release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
+    for (DevBuf* d : {&c->src_flag, &c->src_box, &c->tgt_flag, &c->tgt_finite, &c->nrm_finite, &c->sel_temp, &c->d_count}) release(*d);
+    if (c->pin_up) (void)hipHostFree(c->pin_up);
+    if (c->up_ev) (void)hipEventDestroy(c->up_ev);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->build_ev) if (e) (void)hipEventDestroy(e);
@@ -630,13 +682,10 @@ int icp_set_target(icp_ctx* c, const float* xyz, const float* normals, const uin
     Bvh& b = c->bvh;
     c->bvh6.valid = false;
     b.valid = false; b.n_valid = 0;
-    b.finite_idx.clear(); b.finite_idx.reserve((size_t)n);
-    for (int i = 0; i < n; i++) {         // non-finite targets can never win the strict-< argmin: they stay out of the tree
-        const float* q = xyz + (size_t)i * 3;
-        if (std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2])) b.finite_idx.push_back(i);
-    }
-    b.n_valid = (int)b.finite_idx.size();
-    c->bvh6.finite_idx = b.finite_idx; c->bvh6.n_valid = b.n_valid;
+    // non-finite targets can never win the strict-< argmin: they stay out of the tree (filter + compaction on the device)
+    if ((rc = finite_list(c, c->tgt, false, c->tgt_flag, c->tgt_finite, &b.n_valid))) return rc;
+    b.d_finite = c->tgt_finite.as<int>();
+    c->bvh6.d_finite = b.d_finite; c->bvh6.n_valid = b.n_valid;
     b.attrs = &c->tgt; c->bvh6.attrs = &c->tgt;
     if (c->prm.knn_backend == ICP_KNN_LBVH && c->prm.matching == ICP_MATCH_KNN) {                         // buildIndex; otherwise built on first use
         if (c->prm.color_icp && rgba) return guard.done(build_bvh<6>(c, c->bvh6, target_coords6(c)));
@@ -651,14 +700,17 @@ int icp_set_source(icp_ctx* c, const float* xyz, const float* normals, const uin
     DrainOnError guard(c);
     if ((rc = set_device(c))) return rc;
     if ((rc = upload_cloud(c, c->src, xyz, normals, rgba, n, false))) return rc;
-    c->src_valid.assign((size_t)n, 0);
-    for (int k = 0; k < 3; k++) { c->src_lo[k] = INFINITY; c->src_hi[k] = -INFINITY; }
-    for (int i = 0; i < n; i++) {
-        bool ok = std::isfinite(xyz[(size_t)i * 3]) && std::isfinite(xyz[(size_t)i * 3 + 1]) && std::isfinite(xyz[(size_t)i * 3 + 2]);
-        if (ok) for (int k = 0; k < 3; k++) { const float v = xyz[(size_t)i * 3 + k]; if (v < c->src_lo[k]) c->src_lo[k] = v; if (v > c->src_hi[k]) c->src_hi[k] = v; }
-        if (ok && normals) ok = std::isfinite(normals[(size_t)i * 3]) && std::isfinite(normals[(size_t)i * 3 + 1]) && std::isfinite(normals[(size_t)i * 3 + 2]);
-        c->src_valid[i] = ok ? 1 : 0;
-    }
+    // validity of a source point for the multi-resolution selections (finite point && finite normal, PointCloud.h:334) and the
+    // bounding box of the finite points (Morton order of the queries): both on the device, nothing waits for them here
+    if ((rc = ensure(c, c->src_flag, (size_t)n))) return rc;
+    if ((rc = ensure(c, c->src_box, 32))) return rc;
+    hipLaunchKernelGGL(k_mark_finite, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->src.x.as<float>(), c->src.y.as<float>(), c->src.z.as<float>(),
+                       normals ? c->src.nx.as<float>() : nullptr, normals ? c->src.ny.as<float>() : nullptr, normals ? c->src.nz.as<float>() : nullptr, n, c->src_flag.as<uint8_t>());
+    HIPCK(c, hipMemsetAsync(c->src_box.p, 0xFF, 12, c->stream));
+    HIPCK(c, hipMemsetAsync((char*)c->src_box.p + 12, 0x00, 12, c->stream));
+    hipLaunchKernelGGL(k_bbox, dim3(256), dim3(256), 0, c->stream, c->src.x.as<float>(), c->src.y.as<float>(), c->src.z.as<float>(), n, c->src_box.as<unsigned int>());
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipStreamSynchronize(c->stream));           // entry-point contract: the caller's arrays are free, the stream is idle
     for (auto& kv : c->levels) release(kv.second);
     c->levels.clear();
     return guard.done();
@@ -1019,9 +1071,9 @@ int icp_estimate_normals(icp_ctx* c, const float* xyz, int32_t n, int32_t k, con
     if ((rc = set_device(c))) return rc;
     Cloud& cl = c->nrm_cloud; Bvh& b = c->nrm_bvh;
     if ((rc = upload_cloud(c, cl, xyz, nullptr, nullptr, n, false))) return rc;
-    b.valid = false; b.finite_idx.clear(); b.finite_idx.reserve((size_t)n);
-    for (int i = 0; i < n; i++) { const float* q = xyz + (size_t)i * 3; if (std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2])) b.finite_idx.push_back(i); }
-    b.n_valid = (int)b.finite_idx.size();
+    b.valid = false;
+    if ((rc = finite_list(c, cl, false, c->tgt_flag, c->nrm_finite, &b.n_valid))) return rc;      // (tgt_flag is scratch here: only its list is kept)
+    b.d_finite = c->nrm_finite.as<int>();
     CoordPtrs<3> cp; cp.c[0] = cl.x.as<float>(); cp.c[1] = cl.y.as<float>(); cp.c[2] = cl.z.as<float>();
     if ((rc = build_bvh<3>(c, b, cp))) return rc;
     BvhViewT<3> bv; bv.leaves = b.leaves.as<BvhLeafT<3>>(); bv.nodes = b.nodes.as<BvhNodeT<3>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
