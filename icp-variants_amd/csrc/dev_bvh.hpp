@@ -455,9 +455,8 @@ __device__ __forceinline__ void trav_pop(TravState& st, const unsigned short* __
 // ---- 4-wide walk -------------------------------------------------------------------------------------------------------
 // Same exactness argument as the binary walk (a box is skipped only if its lower bound, computed with the operation order
 // of the point distance, exceeds the running best), half the depth.  Per-lane state: level, index within the level and
-// 4 pending-child bits per level in one 64-bit mask; the pending children's bounds live in LDS as 4 x 16-bit truncated
-// floats per level and lane (one 8-byte access).  Siblings are visited in ascending order of their bound.
-struct QuadState { int L; int idx; unsigned long long pending; bool alive; };
+// 4 pending-child bits per level in one mask register (see quad_run for why bits are enough).
+template <class MaskT> struct QuadStateT { int L; int idx; MaskT pending; bool alive; };     // MaskT: 32 bits hold 8 levels, 64 bits 16
 
 template <int DIM>
 __device__ __forceinline__ void quad_lb(const BvhQuadT<DIM>* __restrict__ nd, const f2* p2, f2& l01, f2& l23) {
@@ -525,26 +524,6 @@ __device__ __forceinline__ void quad_lb_at(const BvhViewT<DIM>& bv, unsigned int
 #endif
 }
 
-// thr: prune threshold derived from the running best (see quad_run)
-__device__ __forceinline__ void quad_pop(QuadState& st, const uint2* __restrict__ lbq, int tid, int nthreads, float thr, float& minlb) {
-    while (!st.alive && st.pending) {
-        const int lv = (63 - __clzll((long long)st.pending)) >> 2;                // deepest level with pending children
-        const unsigned int bits = (unsigned int)(st.pending >> (4 * lv)) & 0xFu;
-        const uint2 w = lbq[lv * nthreads + tid];
-        const float l0 = (bits & 1u) ? __uint_as_float(w.x << 16) : FLT_MAX, l1 = (bits & 2u) ? __uint_as_float(w.x & 0xFFFF0000u) : FLT_MAX;
-        const float l2 = (bits & 4u) ? __uint_as_float(w.y << 16) : FLT_MAX, l3 = (bits & 8u) ? __uint_as_float(w.y & 0xFFFF0000u) : FLT_MAX;
-        const float m = fminf(fminf(l0, l1), fminf(l2, l3));                      // truncated bounds: <= the true ones
-        if (m > thr) {                                                           // the nearest pending sibling is out: so are the others
-            minlb = fminf(minlb, m);
-            st.pending &= ~(0xFull << (4 * lv));
-        } else {
-            const int c = (l0 == m) ? 0 : (l1 == m) ? 1 : (l2 == m) ? 2 : 3;
-            st.pending &= ~(1ull << (4 * lv + c));
-            st.idx = ((st.idx >> (2 * (st.L - lv))) << 2) | c; st.L = lv + 1; st.alive = true;
-        }
-    }
-}
-
 // The walk is a chain of dependent loads, each a trip to L2 or HBM.  A seeded query already knows where it will most
 // likely end up: in or next to the leaf of its previous neighbour, whose ancestors are known arithmetically in the implicit
 // layout.  Touching that whole root-to-leaf path up front turns the chain of misses into ONE round of parallel misses followed
@@ -574,72 +553,70 @@ __device__ __forceinline__ unsigned int quad_prefetch_path(const BvhViewT<DIM>& 
     return sink;
 }
 
-#ifndef ICP_BITS_STACK
-#define ICP_BITS_STACK 0
-#endif
-// ICP_BITS_STACK: the pending siblings are remembered as BITS only (4 per level, one 64-bit register), not with their bounds.
-// A seeded walk is in effect a range query -- its prune threshold is almost final from the first step on -- so re-testing a parked
-// sibling against the improved threshold when it is popped (what the 16-bit bounds in LDS are for) buys next to nothing, while the
-// packing, the LDS round trip and the unpack / min / select of every pop are a third of the walk's instructions.  With bits only a
-// pop is "highest level with a bit set, lowest bit": no loop, no LDS.  A sibling that went stale is noticed one node later (its own
-// children all fail the test), which only costs that node; exactness is untouched (a box is still skipped only on lb > thr, and
-// every skipped box enters minlb when it is tested).
-__device__ __forceinline__ void quad_pop_bits(QuadState& st) {
+// The pending siblings are remembered as BITS only (4 per level, one register), not with their bounds.  A seeded walk is in
+// effect a range query -- its prune threshold is almost final from the first step on -- so re-testing a parked sibling against the
+// improved threshold when it is popped (round 1 kept 16-bit bounds in LDS for that) buys next to nothing, while the packing, the LDS
+// round trip and the unpack / min / select of every pop were a third of the walk's instructions (measured: iterations 1-9 0.091 ->
+// 0.083 ms, the always-walk loop 9.3 k -> 10.6 k iterations/s).  With bits only a pop is "deepest level with a bit set, lowest bit":
+// no loop, no LDS.  A sibling that went stale is noticed one node later (its own children all fail the test), which only costs
+// that node; exactness is untouched (a box is still skipped only on lb > thr, and every skipped box enters minlb when tested).
+template <class MaskT>
+__device__ __forceinline__ void quad_pop_bits(QuadStateT<MaskT>& st) {
     if (!st.alive && st.pending) {
-        const int lv = (63 - __clzll((long long)st.pending)) >> 2;                // deepest level with pending children
+        const int top = sizeof(MaskT) == 8 ? 63 - __clzll((long long)st.pending) : 31 - __clz((int)st.pending);
+        const int lv = top >> 2;                                                  // deepest level with pending children
         const unsigned int bits = (unsigned int)(st.pending >> (4 * lv)) & 0xFu;
         const int c = __ffs((int)bits) - 1;
-        st.pending &= ~(1ull << (4 * lv + c));
+        st.pending &= ~((MaskT)1 << (4 * lv + c));
         st.idx = ((st.idx >> (2 * (st.L - lv))) << 2) | c; st.L = lv + 1; st.alive = true;
     }
 }
-template <int DIM>
-__device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<DIM>& qp, QuadState& st,
-                                         float& best, int& bi, int& bpos, float& best2, float& minlb, uint2* __restrict__ lbq, int tid, int nthreads) {
+#ifndef ICP_DEBUG_STEPS
+#define ICP_DEBUG_STEPS 0        // 1: development build that records nodes + leaves visited per query (icp_debug_steps)
+#endif
+#if ICP_DEBUG_STEPS
+#define ICP_COUNT_STEP(x) ((x)++)
+__device__ int g_dbg_nodes_dummy;
+#else
+#define ICP_COUNT_STEP(x)
+#endif
+template <int DIM, class MaskT>
+__device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<DIM>& qp, QuadStateT<MaskT>& st,
+                                         float& best, int& bi, int& bpos, float& best2, float& minlb, int& dbg_nodes, int& dbg_leaves) {
     const int Lq = bv.Lq;
     // A box is skipped when its lower bound exceeds thr = best * (1 + 2e-5) (clamped so that the +inf bound of an empty box is
     // always skipped): that implies bound > best with margin, one multiply per change of `best` instead of one per box test.
     float thr = fminf(best * 1.00002f, FLT_MAX);
+    // smallest skipped bound, kept as its bit pattern: bounds are >= +0, so unsigned order is value order and the integer minimum
+    // needs none of the NaN canonicalisation a float minimum of selected values drags in
+    unsigned int mlb = __float_as_uint(minlb);
+    constexpr unsigned int NONE = 0x7F800000u;            // +inf
     while (st.alive) {
         while (st.alive && st.L < Lq) {
             f2 l01, l23;
+            ICP_COUNT_STEP(dbg_nodes);
             quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * st.L)) - 1u)) + (unsigned int)st.idx, qp, l01, l23);
             const float m = fminf(fminf(l01.x, l01.y), fminf(l23.x, l23.y));
             const bool s0 = !(l01.x > thr), s1 = !(l01.y > thr), s2 = !(l23.x > thr), s3 = !(l23.y > thr);
-            minlb = fminf(minlb, fminf(fminf(s0 ? FLT_MAX : l01.x, s1 ? FLT_MAX : l01.y), fminf(s2 ? FLT_MAX : l23.x, s3 ? FLT_MAX : l23.y)));   // skipped right here
+            mlb = min(min(mlb, min(s0 ? NONE : __float_as_uint(l01.x), s1 ? NONE : __float_as_uint(l01.y))), min(s2 ? NONE : __float_as_uint(l23.x), s3 ? NONE : __float_as_uint(l23.y)));   // skipped right here
             if (!(m > thr)) {
-                const int c = (l01.x == m) ? 0 : (l01.y == m) ? 1 : (l23.x == m) ? 2 : 3;
+                const bool b0 = l01.x == m, b1 = l01.y == m, b2 = l23.x == m;
+                int c = 3; c = b2 ? 2 : c; c = b1 ? 1 : c; c = b0 ? 0 : c;         // nearest child first (selects, not branches)
                 const unsigned int pend = ((s0 ? 1u : 0u) | (s1 ? 2u : 0u) | (s2 ? 4u : 0u) | (s3 ? 8u : 0u)) & ~(1u << c);
-#if ICP_BITS_STACK
-                st.pending |= (unsigned long long)pend << (4 * st.L);
-#else
-                if (pend) {
-                    uint2 w;
-                    w.x = (__float_as_uint(l01.x) >> 16) | (__float_as_uint(l01.y) & 0xFFFF0000u);
-                    w.y = (__float_as_uint(l23.x) >> 16) | (__float_as_uint(l23.y) & 0xFFFF0000u);
-                    lbq[st.L * nthreads + tid] = w;
-                    st.pending |= (unsigned long long)pend << (4 * st.L);
-                }
-#endif
+                st.pending |= (MaskT)pend << (4 * st.L);
                 st.idx = (st.idx << 2) | c; st.L++;
             } else st.alive = false;                      // all four children pruned
-#if ICP_BITS_STACK
             quad_pop_bits(st);
-#else
-            quad_pop(st, lbq, tid, nthreads, thr, minlb);
-#endif
         }
         if (st.alive) {
+            ICP_COUNT_STEP(dbg_leaves);
             leaf_eval<DIM>(bv.leaves + st.idx, st.idx, qp.p2, best, bi, bpos, best2);
             thr = fminf(best * 1.00002f, FLT_MAX);
             st.alive = false;
-#if ICP_BITS_STACK
             quad_pop_bits(st);
-#else
-            quad_pop(st, lbq, tid, nthreads, thr, minlb);
-#endif
         }
     }
+    minlb = __uint_as_float(mlb);
 }
 
 // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (block b runs on the XCD group b % 8), each
@@ -784,7 +761,8 @@ __device__ __forceinline__ bool coop_search(const BvhViewT<DIM>& bv, const float
 // The tree walk proper for query p, starting from the seed (best, bi, bpos); returns the lower bound on the distance to every
 // target other than the winner.  NT = threads of the block (layout of the LDS stacks).
 template <int DIM, int NT>
-__device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* p, float& best, int& bi, int& bpos, uint2* __restrict__ lbq, int tid) {
+__device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* p, float& best, int& bi, int& bpos, uint2* __restrict__ lbq, int tid, int* dbg_out = nullptr) {
+    int dbg_nodes = 0, dbg_leaves = 0;
     QueryPt<DIM> qp;
     make_query<DIM>(bv, p, qp);
     float best2 = FLT_MAX, minlb = FLT_MAX;
@@ -805,8 +783,16 @@ __device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* 
         leaf_eval<DIM>(bv.leaves + idx, idx, qp.p2, best, bi, bpos, unused);      // (the walk re-evaluates this leaf: the bound bookkeeping stays in one place)
     }
     if (ICP_PREFETCH_PATH && bpos >= 0) touched = quad_prefetch_path<DIM>(bv, bpos >> 3);
-    QuadState st; st.L = 0; st.idx = 0; st.pending = 0ull; st.alive = true;
-    quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, minlb, lbq, tid, NT);
+    if (bv.Lq <= 8) {                                     // uniform: up to 8 levels (524 288 targets) the pending bits fit 32 bits
+        QuadStateT<unsigned int> st; st.L = 0; st.idx = 0; st.pending = 0u; st.alive = true;
+        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, minlb, dbg_nodes, dbg_leaves);
+    } else {
+        QuadStateT<unsigned long long> st; st.L = 0; st.idx = 0; st.pending = 0ull; st.alive = true;
+        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, minlb, dbg_nodes, dbg_leaves);
+    }
+#if ICP_DEBUG_STEPS
+    if (dbg_out) *dbg_out = dbg_nodes | (dbg_leaves << 16);
+#endif
     asm volatile("" ::"v"(touched));
     return sqrtf(fminf(best2, minlb)) * 0.999999f;
 }

@@ -101,7 +101,10 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
             }
         }
     }
-    if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, bvh_lbq, tid);
+#if ICP_DEBUG_STEPS
+    if (k >= 0 && kp.dbg_steps) kp.dbg_steps[k] = need_walk ? -1 : 0;      // -1: a cooperative search took it (overwritten by a per-lane walk)
+#endif
+    if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, bvh_lbq, tid, (ICP_DEBUG_STEPS && kp.dbg_steps) ? kp.dbg_steps + k : nullptr);
     if (k >= 0) {
         // A verified query keeps its stored anchor (position of the last full search) and bound: the triangle test stays valid
         // against the OLD anchor -- and is tighter than re-anchoring, (L - d1) - d2 <= L - |d1 + d2| -- and its neighbour is

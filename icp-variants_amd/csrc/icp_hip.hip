@@ -84,6 +84,7 @@ struct icp_ctx {
     std::map<int, Level> levels;         // multires selections by decimation factor
     DevBuf sel_lists, sel_counts, sel_blocks;            // RANDOM_SAMPLING: per-iteration index lists, their sizes, scan scratch
     DevBuf qstate;                                       // incremental k-NN: per-query position + bound on the other targets
+    DevBuf dbg_steps;                    // development builds only (ICP_DEBUG_STEPS)
     DevBuf ps, matches, d2, best64, nn_raw, partials, totals, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
     Cloud conv_src, conv_ref; int conv_n = 0;
     float cos_reject = 0.5f;
@@ -431,11 +432,15 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr) {
     kp.tx = c->tgt.x.as<float>(); kp.ty = c->tgt.y.as<float>(); kp.tz = c->tgt.z.as<float>();
     kp.tcr = c->tgt.cr.as<float>(); kp.tcg = c->tgt.cg.as<float>(); kp.tcb = c->tgt.cb.as<float>();
     kp.mpad = c->tgt.npad; kp.ps = c->ps.as<PoseState>(); kp.pretransformed = q.pretransformed; kp.max_dist = p.max_distance;
-    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0; kp.qstate = nullptr; kp.incremental = 0;
+    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0; kp.qstate = nullptr; kp.incremental = 0; kp.dbg_steps = nullptr;
     if (p.knn_backend == ICP_KNN_LBVH) {
         kp.nseg = 1;
         if ((rc = ensure(c, c->nn_raw, (size_t)q.n * 4))) return rc;
         kp.nn_raw = c->nn_raw.as<int>(); kp.use_prev = q.seed_prev ? 1 : 0;
+#if ICP_DEBUG_STEPS
+        if ((rc = ensure(c, c->dbg_steps, (size_t)q.n * 4))) return rc;
+        kp.dbg_steps = c->dbg_steps.as<int>();
+#endif
         if (p.knn_incremental && !q.pretransformed) {
             if ((rc = ensure(c, c->qstate, (size_t)q.n * 16))) return rc;
             kp.qstate = c->qstate.as<float4>(); kp.incremental = 1;
@@ -646,7 +651,7 @@ int icp_ctx_destroy(icp_ctx* c) {
     for (Bvh* b : {&c->bvh6, &c->nrm_bvh}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
     release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) release(kv.second);
-    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->sums);
+    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->dbg_steps); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
     for (DevBuf* d : {&c->src_flag, &c->src_box, &c->tgt_flag, &c->tgt_finite, &c->nrm_finite, &c->sel_temp, &c->d_count}) release(*d);
     if (c->pin_up) (void)hipHostFree(c->pin_up);
@@ -1113,6 +1118,16 @@ static int transform_common(icp_ctx* c, const float* in, int32_t n, const float 
     HIPCK(c, hipStreamSynchronize(c->stream));
     return guard.done();
 }
+// Development builds (ICP_DEBUG_STEPS=1): nodes | leaves << 16 visited by the walk of each query of the LAST matcher launch, in the
+// order the launch indexed its queries (Morton order for a run); 0 = verified without a walk, -1 = cooperative search.
+int icp_debug_steps(icp_ctx* c, int32_t* out, int32_t n) {
+    if (!c || !out || n <= 0 || !c->dbg_steps.p || (size_t)n * 4 > c->dbg_steps.cap) return ICP_ERR_INVALID_ARG;
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    HIPCK(c, hipMemcpy(out, c->dbg_steps.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return ICP_OK;
+}
+
 // ---- hardware self test (not part of icp_hip.h; called by tests/ through ctypes) ------------------------------------------
 // One wave folds n_values (<= 32) doubles per lane with wave_transpose_reduce_gen; out[v] = the wave total of value v read from
 // the lane wave_value_of_lane says holds it.  tests/test_gpu_selftest.py replays the same pairing with numpy: bit-identical.

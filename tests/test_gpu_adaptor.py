@@ -71,6 +71,7 @@ def test_batch_and_gather_from_a_cxx14_host(tmp_path, orc):
             for k in ("src", "tgt"):
                 f.write(np.int32(len(d[k + "_pts"])).tobytes()); f.write(d[k + "_pts"].astype(np.float32).tobytes()); f.write(d[k + "_nrm"].astype(np.float32).tobytes())
     out = subprocess.check_output([build_batch_driver(str(tmp_path)), dump, "3", "25"]).decode().splitlines()
+    out = [ln for ln in out if ln.startswith(("batch rc", "gather rc", "pose "))]        # (RCCL prints its version banner on stdout)
     assert out[0] == "batch rc 0" and out[1].startswith("gather rc 0")
     for p, d in enumerate(pairs):
         tok = out[2 + p].split()
