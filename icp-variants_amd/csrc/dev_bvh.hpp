@@ -571,9 +571,6 @@ __device__ __forceinline__ void quad_pop_bits(QuadStateT<MaskT>& st) {
         st.idx = ((st.idx >> (2 * (st.L - lv))) << 2) | c; st.L = lv + 1; st.alive = true;
     }
 }
-#ifndef ICP_CHILD_ORDER_FIXED
-#define ICP_CHILD_ORDER_FIXED 0    // 1: visit the surviving children in index order instead of nearest first (development A/B)
-#endif
 #ifndef ICP_DEBUG_STEPS
 #define ICP_DEBUG_STEPS 0        // 1: development build that records nodes + leaves visited per query (icp_debug_steps)
 #endif
@@ -603,15 +600,11 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<
             const bool s0 = !(l01.x > thr), s1 = !(l01.y > thr), s2 = !(l23.x > thr), s3 = !(l23.y > thr);
             mlb = min(min(mlb, min(s0 ? NONE : __float_as_uint(l01.x), s1 ? NONE : __float_as_uint(l01.y))), min(s2 ? NONE : __float_as_uint(l23.x), s3 ? NONE : __float_as_uint(l23.y)));   // skipped right here
             if (!(m > thr)) {
-#if ICP_CHILD_ORDER_FIXED
-                const unsigned int sm = (s0 ? 1u : 0u) | (s1 ? 2u : 0u) | (s2 ? 4u : 0u) | (s3 ? 8u : 0u);
-                const int c = __ffs((int)sm) - 1;                                 // lowest surviving child first
-                const unsigned int pend = sm & (sm - 1u);
-#else
+                // nearest child first (selects, not branches).  Measured: taking the survivors in index order instead saves 5 instructions
+                // per node and costs 0.080 -> 0.096 ms in iterations 1-9 (0.17 -> 0.80 ms unseeded): the order is worth its price.
                 const bool b0 = l01.x == m, b1 = l01.y == m, b2 = l23.x == m;
-                int c = 3; c = b2 ? 2 : c; c = b1 ? 1 : c; c = b0 ? 0 : c;         // nearest child first (selects, not branches)
+                int c = 3; c = b2 ? 2 : c; c = b1 ? 1 : c; c = b0 ? 0 : c;
                 const unsigned int pend = ((s0 ? 1u : 0u) | (s1 ? 2u : 0u) | (s2 ? 4u : 0u) | (s3 ? 8u : 0u)) & ~(1u << c);
-#endif
                 st.pending |= (MaskT)pend << (4 * st.L);
                 st.idx = (st.idx << 2) | c; st.L++;
             } else st.alive = false;                      // all four children pruned
