@@ -21,7 +21,7 @@
 #define ICP_SEED_DESCENT 1
 #endif
 #ifndef ICP_COOP_MAX
-#define ICP_COOP_MAX 2          // a wave with at most this many (seeded) queries left to search does them cooperatively; 0 = never
+#define ICP_COOP_MAX 8          // a wave with at most this many (seeded) queries left to search does them cooperatively, one per lane group; 0 = never
 #endif
 #ifndef ICP_PREFETCH_PATH
 #define ICP_PREFETCH_PATH 1
@@ -702,62 +702,83 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, WAVE));
     return v;
 }
+// Generalised to GROUPS of lanes: the wave is split into G = 64 / S aligned groups of S lanes (S = 64, 32, 16 or 8) and every
+// group searches ONE query, all groups at once.  A wave with up to 8 unverified queries finishes them in about Lq + 2 dependent
+// steps instead of the longest of their walks (20-50 steps): once most queries verify, these few walks are what an iteration waits
+// for.  Per group: own frontier in its share of the wave's stack slots (Lq * S entries per buffer), ballots masked to the group's
+// lanes, group-wide minima by xor-shuffles that stay inside the aligned group.  gact: this lane's group has a query; q, best, bi,
+// bpos: that query and its seed, identical in all lanes of the group.  Returns (per lane, uniform in the group) whether the search
+// completed; false (outputs untouched) when the group's frontier would overflow -> that query falls back to the per-lane walk.
 template <int DIM, int NT>
-__device__ __forceinline__ bool coop_search(const BvhViewT<DIM>& bv, const float* q /* wave-uniform */, float& best, int& bi, int& bpos, float& lb_others,
+__device__ __forceinline__ bool coop_search(const BvhViewT<DIM>& bv, const float* q, bool gact, int lgS, float& best, int& bi, int& bpos, float& lb_others,
                                             uint2* __restrict__ lbq, int tid) {
     const int lane = tid & 63, wbase = tid & ~63;          // this wave's slots: lbq[row * NT + wbase + col]
-    const int Lq = bv.Lq, cap = Lq * WAVE;
+    const int S = 1 << lgS, gl = lane & (S - 1), g = lane >> lgS;
+    const unsigned long long gm = (lgS == 6 ? ~0ull : ((1ull << S) - 1ull)) << (g * S);          // the lanes of my group
+    const unsigned long long lt = gm & ((1ull << lane) - 1ull);                                   // ... below me
+    const int Lq = bv.Lq, cap = Lq << lgS;                 // entries per buffer and group
     QueryPt<DIM> qp;
     make_query<DIM>(bv, q, qp);
     const float thr = fminf(best * 1.00002f, FLT_MAX);
     float minlb = FLT_MAX;
-    unsigned int* slot = (unsigned int*)lbq;               // entry e of buffer b: slot[2 * ((e >> 6) * NT + wbase + (e & 63)) + b]
-    int n = 1, cur = 0;
-    if (lane == 0) slot[2 * (wbase) + 0] = 0u;
+    unsigned int* slot = (unsigned int*)lbq;               // entry E of buffer b: slot[2 * ((E >> 6) * NT + wbase + (E & 63)) + b]; group g owns E in [g * cap, (g + 1) * cap)
+    const int e0 = g * cap;
+    int n = gact ? 1 : 0, cur = 0;
+    bool ok = gact;
+    if (gl == 0 && gact) slot[2 * ((e0 >> 6) * NT + wbase + (e0 & 63)) + 0] = 0u;
     for (int L = 0; L < Lq; L++) {
-        int nn = 0;                                        // wave-uniform size of the next frontier
-        for (int base = 0; base < n; base += WAVE) {
-            const int e = base + lane;
-            const bool act = e < n;
-            const unsigned int node = act ? slot[2 * ((e >> 6) * NT + wbase + (e & 63)) + cur] : 0u;
+        int nn = 0;                                        // group-uniform size of the next frontier
+        for (int base = 0; __any(ok && base < n); base += S) {
+            const int e = base + gl;
+            const bool act = ok && e < n;
+            const int E = e0 + e;
+            const unsigned int node = act ? slot[2 * ((E >> 6) * NT + wbase + (E & 63)) + cur] : 0u;
             f2 l01, l23;
             quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * L)) - 1u)) + node, qp, l01, l23);
             const bool s0 = act && !(l01.x > thr), s1 = act && !(l01.y > thr), s2 = act && !(l23.x > thr), s3 = act && !(l23.y > thr);
             if (act) minlb = fminf(minlb, fminf(fminf(s0 ? FLT_MAX : l01.x, s1 ? FLT_MAX : l01.y), fminf(s2 ? FLT_MAX : l23.x, s3 ? FLT_MAX : l23.y)));
-            const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1), m2 = __ballot(s2), m3 = __ballot(s3);
+            const unsigned long long m0 = __ballot(s0) & gm, m1 = __ballot(s1) & gm, m2 = __ballot(s2) & gm, m3 = __ballot(s3) & gm;
             const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
-            if (nn + c0 + c1 + c2 + c3 > cap) return false;                                   // uniform
-            const unsigned long long lt = (1ull << lane) - 1ull;
+            if (nn + c0 + c1 + c2 + c3 > cap) ok = false;                                     // uniform in the group: it gives up
             const int o0 = nn + __popcll(m0 & lt), o1 = nn + c0 + __popcll(m1 & lt), o2 = nn + c0 + c1 + __popcll(m2 & lt), o3 = nn + c0 + c1 + c2 + __popcll(m3 & lt);
             const unsigned int ch = node << 2;
-            if (s0) slot[2 * ((o0 >> 6) * NT + wbase + (o0 & 63)) + (cur ^ 1)] = ch;
-            if (s1) slot[2 * ((o1 >> 6) * NT + wbase + (o1 & 63)) + (cur ^ 1)] = ch | 1u;
-            if (s2) slot[2 * ((o2 >> 6) * NT + wbase + (o2 & 63)) + (cur ^ 1)] = ch | 2u;
-            if (s3) slot[2 * ((o3 >> 6) * NT + wbase + (o3 & 63)) + (cur ^ 1)] = ch | 3u;
+            if (ok) {
+                if (s0) { const int F = e0 + o0; slot[2 * ((F >> 6) * NT + wbase + (F & 63)) + (cur ^ 1)] = ch; }
+                if (s1) { const int F = e0 + o1; slot[2 * ((F >> 6) * NT + wbase + (F & 63)) + (cur ^ 1)] = ch | 1u; }
+                if (s2) { const int F = e0 + o2; slot[2 * ((F >> 6) * NT + wbase + (F & 63)) + (cur ^ 1)] = ch | 2u; }
+                if (s3) { const int F = e0 + o3; slot[2 * ((F >> 6) * NT + wbase + (F & 63)) + (cur ^ 1)] = ch | 3u; }
+            }
             nn += c0 + c1 + c2 + c3;
         }
         n = nn; cur ^= 1;
-        if (n == 0) break;
+        if (!__any(ok && n > 0)) break;
     }
-    // leaves: one per lane and round; every lane starts from the seed
+    // leaves: one per lane and round; every lane starts from its group's seed
     float b = best, b2 = FLT_MAX; int i = bi, ps = bpos;
-    for (int base = 0; base < n; base += WAVE) {
-        const int e = base + lane;
-        if (e < n) {
-            const int leaf = (int)slot[2 * ((e >> 6) * NT + wbase + (e & 63)) + cur];
+    for (int base = 0; __any(ok && base < n); base += S) {
+        const int e = base + gl;
+        if (ok && e < n) {
+            const int E = e0 + e;
+            const int leaf = (int)slot[2 * ((E >> 6) * NT + wbase + (E & 63)) + cur];
             leaf_eval<DIM>(bv.leaves + leaf, leaf, qp.p2, b, i, ps, b2);
         }
     }
-    const float wb = wave_min_f32(b);
-    const int wi = wave_min_i32(b == wb ? i : 0x7FFFFFFF);
+    // minima over the group (xor-shuffles below S stay inside the aligned group)
+    float wb = b;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(wb, o, WAVE); if (o < S) wb = fminf(wb, t); }
+    int wi = (b == wb) ? i : 0x7FFFFFFF;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(wi, o, WAVE); if (o < S) wi = min(wi, t); }
     const bool mine = (b == wb) && (i == wi);             // lanes holding the winner (several if it is the seed)
-    const int wl = __ffsll((long long)__ballot(mine)) - 1;
-    const int wps = __shfl(ps, wl, WAVE);
-    const float others = wave_min_f32(mine ? b2 : fminf(b, b2));      // a lane whose local winner lost: that point is an "other" too
-    minlb = wave_min_f32(minlb);
-    best = wb; bi = wi; bpos = wps;
-    lb_others = sqrtf(fminf(others, minlb)) * 0.999999f;
-    return true;
+    const unsigned long long mm = __ballot(mine) & gm;
+    const int wl = __ffsll((long long)mm) - 1;
+    const int wps = __shfl(ps, wl < 0 ? lane : wl, WAVE);
+    float others = mine ? b2 : fminf(b, b2);              // a lane whose local winner lost: that point is an "other" too
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(others, o, WAVE), u = __shfl_xor(minlb, o, WAVE); if (o < S) { others = fminf(others, t); minlb = fminf(minlb, u); } }
+    if (ok) { best = wb; bi = wi; bpos = wps; lb_others = sqrtf(fminf(others, minlb)) * 0.999999f; }
+    return ok;
 }
 
 // The tree walk proper for query p, starting from the seed (best, bi, bpos); returns the lower bound on the distance to every

@@ -83,22 +83,30 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
             }
         }
     }
-    // ---- the walks.  A wave left with only a few seeded queries to search does them cooperatively, one after the other
-    // (coop_search); otherwise every lane walks on its own.
+    // ---- the walks.  A wave left with at most ICP_COOP_MAX seeded queries to search does them cooperatively, all at once, one per
+    // group of lanes (coop_search); otherwise every lane walks on its own.
     {
-        unsigned long long wm = __ballot(need_walk);
+        const unsigned long long wm = __ballot(need_walk);
         const unsigned long long cm = __ballot(need_walk && bpos >= 0);
-        if (ICP_COOP_MAX > 0 && wm != 0ull && wm == cm && __popcll(wm) <= ICP_COOP_MAX && bv.Lq > 0) {
-            const int lane = tid & 63;
-            while (wm) {
-                const int src = __ffsll((long long)wm) - 1; wm &= wm - 1ull;
-                float q[DIM];
+        const int W = __popcll(wm);
+        if (ICP_COOP_MAX > 0 && W > 0 && wm == cm && W <= ICP_COOP_MAX && bv.Lq > 0) {
+            const int lgS = W == 1 ? 6 : W == 2 ? 5 : W <= 4 ? 4 : 3;                 // 1 / 2 / 4 / 8 groups of 64 / 32 / 16 / 8 lanes
+            const int g = lane >> lgS;
+            unsigned long long rest = wm;                                            // source lane of my group: the g-th walker
+            for (int t = 0; t < g && t < 7; t++) rest &= rest - 1ull;
+            const bool gact = g < W;
+            const int src = gact ? __ffsll((long long)rest) - 1 : lane;
+            float q[DIM];
 #pragma unroll
-                for (int a = 0; a < DIM; a++) q[a] = __shfl(p[a], src, WAVE);
-                float b = __shfl(best, src, WAVE), lbo = 0.f; int ci = __shfl(bi, src, WAVE), cps = __shfl(bpos, src, WAVE);
-                const bool done = coop_search<DIM, BVH_THREADS>(bv, q, b, ci, cps, lbo, bvh_lbq, tid);      // wave-uniform
-                if (done && lane == src) { best = b; bi = ci; bpos = cps; lb_others = lbo; need_walk = false; }
-            }
+            for (int a = 0; a < DIM; a++) q[a] = __shfl(p[a], src, WAVE);
+            float b = __shfl(best, src, WAVE), lbo = 0.f; int ci = __shfl(bi, src, WAVE), cps = __shfl(bpos, src, WAVE);
+            const bool done = coop_search<DIM, BVH_THREADS>(bv, q, gact, lgS, b, ci, cps, lbo, bvh_lbq, tid);
+            // the result travels back to the source lane: it reads it from the first lane of the group that searched for it
+            const int gsrc = __popcll(wm & ((1ull << lane) - 1ull));                 // my rank among the walkers = the group that served me
+            const int from = min(gsrc, 7) << lgS;
+            const float rb = __shfl(b, from, WAVE), rl = __shfl(lbo, from, WAVE); const int ri = __shfl(ci, from, WAVE), rp = __shfl(cps, from, WAVE);
+            const bool rdone = __shfl((int)done, from, WAVE) != 0;
+            if (need_walk && rdone) { best = rb; bi = ri; bpos = rp; lb_others = rl; need_walk = false; }
         }
     }
 #if ICP_DEBUG_STEPS
