@@ -289,6 +289,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="batch mode (configs[3]): align this many consecutive scan pairs per step, "
                     "sharded pair p -> rank p mod N, uploads and index builds INSIDE the timed region, one pose gather per step")
     ap.add_argument("--gather", choices=["cabi", "torch"], default="cabi", help="pose gather: ncclAllGather from the C ABI (default) or torch.distributed")
+    ap.add_argument("--no-extras", action="store_true", help="skip the legs outside the timed region (per-iteration records, the always-walk comparison run): "
+                    "for profiling, so that a kernel trace holds the launches of the warm-up and timed steps only")
     ap.add_argument("--dry-run", action="store_true", help="no device: rehearse the N-rank sharding + pose gather on CPU (gloo)")
     ap.add_argument("--eth-dir", default=None, help="directory with <name>_global.csv and <name>/<scan>.pcd (the reference's Data/eth layout): "
                     "run the configs[1] settings on real ETH scans instead of the synthetic pair")
@@ -385,7 +387,9 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    _, recs, _ = ctx.run(binding.pose_from_c(eye), check=False)         # after the timed region: per-iteration records for the line
+    recs = []
+    if not args.no_extras:
+        _, recs, _ = ctx.run(binding.pose_from_c(eye), check=False)     # after the timed region: per-iteration records for the line
 
     iters_total = world * R * args.steps * args.iterations
     value = iters_total / elapsed
@@ -459,7 +463,7 @@ def main():
         out["valu_roofline"] = {"pair_evals_per_s": pairs / (knn_ms * 1e-3), "achieved_tflops": flops / (knn_ms * 1e-3) / 1e12,
                                 "peak_tflops": FP32_VALU_PEAK_TFLOPS,
                                 "note": "brute force is FP32-VALU-bound, not HBM-bound (SURVEY.md 8d); 8 non-fused flop per pair"}
-    if rank == 0 and world == 1 and fused and not args.no_incremental:
+    if rank == 0 and world == 1 and fused and not args.no_incremental and not args.no_extras:
         # the same workload with the verify-and-skip test off (every query walks the tree in every iteration): outside the timed region
         o2 = make_optimizer(binding, local_rank, args, incremental=False)
         o2.ctx.set_stage_timing(0)

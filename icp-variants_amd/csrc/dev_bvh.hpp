@@ -17,6 +17,9 @@
 //           monotonicity of IEEE rounding fl(d2(point)) >= fl(lb) for every point in the box (a 2e-5 relative margin is
 //           kept on top).  Equal distances resolve to the lowest original index, exactly like the strict-< scan
 //           (NearestNeighbor.h:87).
+#ifndef ICP_ISEL_NATURAL
+#define ICP_ISEL_NATURAL 0        // 1: the natural spellings of two expressions in k_bvh_block_levels that crash the ROCm 7.2 gfx950 instruction selector
+#endif
 #ifndef ICP_SEED_DESCENT
 #define ICP_SEED_DESCENT 1
 #endif
@@ -27,7 +30,10 @@
 #define ICP_PREFETCH_PATH 1
 #endif
 constexpr int BVH_LEAF = 8;
-constexpr int BVH_THREADS = 128;
+#ifndef ICP_BVH_THREADS
+#define ICP_BVH_THREADS 128
+#endif
+constexpr int BVH_THREADS = ICP_BVH_THREADS;    // queries per block of the BVH matchers
 
 template <int DIM> struct BvhNodeT { float lo[DIM][2]; float hi[DIM][2]; float pad[DIM == 3 ? 4 : 8]; };   // 64 B / 128 B
 template <int DIM> struct BvhLeafT { float c[DIM][BVH_LEAF]; int idx[BVH_LEAF]; float pad[DIM == 3 ? 0 : 8]; };   // 128 B / 256 B
@@ -208,8 +214,14 @@ __global__ __launch_bounds__(BLV_THREADS) void k_bvh_block_levels(const CoordPtr
 #pragma unroll
         for (int k = 0; k < DIM; k++) {
             // from_ordered_bits spelled with ^ instead of & 0x7FFFFFFF: the other spelling crashes the gfx950 instruction selector here
+            // (ROCm 7.2).  tests/test_compiler_workarounds.py compiles the natural spellings (ICP_ISEL_NATURAL=1) and reports whether
+            // the crash is still there; the GPU parity tests of the BVH cover the results of this spelling.
             const unsigned int uh = hi[k], ul = lo[k];
+#if ICP_ISEL_NATURAL
+            const float fh = from_ordered_bits(uh), fl = from_ordered_bits(ul);
+#else
             const float fh = __uint_as_float((uh & 0x80000000u) ? (uh ^ 0x80000000u) : ~uh), fl = __uint_as_float((ul & 0x80000000u) ? (ul ^ 0x80000000u) : ~ul);
+#endif
             const float e = fh - fl;
             if (e > ext) { ext = e; axis = k; }
         }
@@ -217,9 +229,13 @@ __global__ __launch_bounds__(BLV_THREADS) void k_bvh_block_levels(const CoordPtr
             const int pos = tid * BLV_PER + q, j = vals[pos];
             unsigned long long key = ~0ull;
             if (j >= 0) {
+#if ICP_ISEL_NATURAL
+                const float c = cp.c[axis][j];
+#else
                 float c = cp.c[0][j];
 #pragma unroll
                 for (int k = 1; k < DIM; k++) c = (axis == k) ? cp.c[k][j] : c;      // (selecting the plane POINTER instead crashes the gfx950 instruction selector)
+#endif
                 key = ((unsigned long long)ordered_bits(c) << 32) | (unsigned int)pos;
             }
             keys[pos] = key;

@@ -89,11 +89,12 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
         const unsigned long long wm = __ballot(need_walk);
         const unsigned long long cm = __ballot(need_walk && bpos >= 0);
         const int W = __popcll(wm);
+        static_assert(ICP_COOP_MAX <= 16, "at most 16 lane groups");
         if (ICP_COOP_MAX > 0 && W > 0 && wm == cm && W <= ICP_COOP_MAX && bv.Lq > 0) {
-            const int lgS = W == 1 ? 6 : W == 2 ? 5 : W <= 4 ? 4 : 3;                 // 1 / 2 / 4 / 8 groups of 64 / 32 / 16 / 8 lanes
+            const int lgS = W == 1 ? 6 : W == 2 ? 5 : W <= 4 ? 4 : W <= 8 ? 3 : 2;     // 1 / 2 / 4 / 8 / 16 groups of 64 / 32 / 16 / 8 / 4 lanes
             const int g = lane >> lgS;
             unsigned long long rest = wm;                                            // source lane of my group: the g-th walker
-            for (int t = 0; t < g && t < 7; t++) rest &= rest - 1ull;
+            for (int t = 0; t < g && t < 15; t++) rest &= rest - 1ull;
             const bool gact = g < W;
             const int src = gact ? __ffsll((long long)rest) - 1 : lane;
             float q[DIM];
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
             const bool done = coop_search<DIM, BVH_THREADS>(bv, q, gact, lgS, b, ci, cps, lbo, bvh_lbq, tid);
             // the result travels back to the source lane: it reads it from the first lane of the group that searched for it
             const int gsrc = __popcll(wm & ((1ull << lane) - 1ull));                 // my rank among the walkers = the group that served me
-            const int from = min(gsrc, 7) << lgS;
+            const int from = min(gsrc, 15) << lgS;
             const float rb = __shfl(b, from, WAVE), rl = __shfl(lbo, from, WAVE); const int ri = __shfl(ci, from, WAVE), rp = __shfl(cps, from, WAVE);
             const bool rdone = __shfl((int)done, from, WAVE) != 0;
             if (need_walk && rdone) { best = rb; bi = ri; bpos = rp; lb_others = rl; need_walk = false; }

@@ -487,17 +487,23 @@ int launch_post_and_solve(icp_ctx* c, const Cloud& src, const int* sel, int n, i
     sp.partials = c->partials.as<double>(); sp.nblocks = nb; sp.ps = c->ps.as<PoseState>(); sp.metric = p.metric;
     sp.totals = c->totals.as<double>(); sp.ticket = (unsigned*)(c->totals.as<double>() + NSUM);
     sp.n_src = n; sp.update_pose = update_pose;
+    // few partials: one block does it all (no hand-over between blocks); many: one block per sum + last-arriver solve
+    const bool one_block = nb <= R1_PER_SUM * R1_MAXLOADS;
+    auto reduce_solve = [&]() {
+        if (one_block) hipLaunchKernelGGL(k_reduce_solve_1b, dim3(1), dim3(R1_THREADS), 0, c->stream, sp);
+        else hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM_USED), dim3(SOLVE_THREADS), 0, c->stream, sp);
+    };
     if (p.metric == ICP_METRIC_SYMMETRIC) {
         sp.phase = 0; sp.stats = nullptr; sp.sums_out = nullptr;
-        hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM_USED), dim3(SOLVE_THREADS), 0, c->stream, sp);       // means
+        reduce_solve();                                                                              // means
         hipLaunchKernelGGL(k_sym_accumulate, dim3(nb), dim3(POST_THREADS), 0, c->stream, pp);
         if (ev_after_post) HIPCK(c, hipEventRecord(ev_after_post, c->stream));
         sp.phase = 1; sp.stats = d_stats; sp.sums_out = d_sums_out;
-        hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM_USED), dim3(SOLVE_THREADS), 0, c->stream, sp);
+        reduce_solve();
     } else {
         if (ev_after_post) HIPCK(c, hipEventRecord(ev_after_post, c->stream));
         sp.phase = 0; sp.stats = d_stats; sp.sums_out = d_sums_out;
-        hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM_USED), dim3(SOLVE_THREADS), 0, c->stream, sp);
+        reduce_solve();
     }
     HIPCK(c, hipGetLastError());
     return ICP_OK;

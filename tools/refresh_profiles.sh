@@ -12,7 +12,7 @@ run bench_brute python bench.py --knn brute --steps 2 --no-cpu-baseline
 run bench_batch16 python bench.py --pairs 16 --steps 3 --warmup 1
 run bench_lbvh_2pairs python bench.py --resident-pairs 2 --no-cpu-baseline
 echo "== kernel trace"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --stage-timing 0 > $OUT/kt.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $OUT/kt.log 2>&1 || exit 1
 find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/lbvh_kernel_stats.csv \;
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktb -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --knn brute > $OUT/ktb.log 2>&1 || exit 1
 find $OUT/ktb -name "*kernel_stats.csv" -exec cp {} $OUT/brute_kernel_stats.csv \;
