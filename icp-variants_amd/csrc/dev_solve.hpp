@@ -461,30 +461,6 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
     solve_tail(sp, tot);
 }
 
-// The same reduction + solve as ONE block, for producers that leave at most R1_PER_SUM * R1_MAXLOADS block partials (k_post's 512;
-// the fused matcher when it runs with large blocks): 30 threads per sum, every thread's loads in flight together (one round trip),
-// fixed add orders, totals through LDS -- no ticket, no publish / re-load hand-over between blocks.
-constexpr int R1_THREADS = 1024, R1_PER_SUM = 30, R1_MAXLOADS = 32;
-__global__ __launch_bounds__(R1_THREADS) void k_reduce_solve_1b(const SolveParams sp) {
-    __shared__ double part[NSUM_USED][R1_PER_SUM];
-    __shared__ double tot[NSUM];
-    const int t = threadIdx.x, a = t / R1_PER_SUM, j = t % R1_PER_SUM;
-    if (a < NSUM_USED) {
-        const double* __restrict__ row = sp.partials + (size_t)a * sp.nblocks;
-        double v[R1_MAXLOADS];
-#pragma unroll
-        for (int u = 0; u < R1_MAXLOADS; u++) { const int b = j + u * R1_PER_SUM; v[u] = b < sp.nblocks ? row[b] : 0.0; }
-        double x = 0.0;
-#pragma unroll
-        for (int u = 0; u < R1_MAXLOADS; u++) { const int b = j + u * R1_PER_SUM; if (b < sp.nblocks) x += v[u]; }
-        part[a][j] = x;
-    }
-    __syncthreads();
-    if (t < NSUM) {
-        double x = 0.0;
-        if (t < NSUM_USED) { for (int q = 0; q < R1_PER_SUM; q++) x += part[t][q]; }
-        tot[t] = x;
-    }
-    __syncthreads();
-    solve_tail(sp, tot);
-}
+// Measured and NOT adopted (round 2): the same reduction + solve as ONE block of 1024 threads for producers that leave few partials
+// (k_post's 512; the fused matcher with 512-thread blocks, 724 partials) -- no hand-over between blocks, but 8.1-9.0 us against
+// 7.4 us for the 34-block form (and the matcher itself is slower with 256- / 512-thread blocks: 22.1 k / 20.3 k vs 22.6 k it/s).

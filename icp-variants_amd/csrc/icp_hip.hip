@@ -487,12 +487,7 @@ int launch_post_and_solve(icp_ctx* c, const Cloud& src, const int* sel, int n, i
     sp.partials = c->partials.as<double>(); sp.nblocks = nb; sp.ps = c->ps.as<PoseState>(); sp.metric = p.metric;
     sp.totals = c->totals.as<double>(); sp.ticket = (unsigned*)(c->totals.as<double>() + NSUM);
     sp.n_src = n; sp.update_pose = update_pose;
-    // few partials: one block does it all (no hand-over between blocks); many: one block per sum + last-arriver solve
-    const bool one_block = nb <= R1_PER_SUM * R1_MAXLOADS;
-    auto reduce_solve = [&]() {
-        if (one_block) hipLaunchKernelGGL(k_reduce_solve_1b, dim3(1), dim3(R1_THREADS), 0, c->stream, sp);
-        else hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM_USED), dim3(SOLVE_THREADS), 0, c->stream, sp);
-    };
+    auto reduce_solve = [&]() { hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM_USED), dim3(SOLVE_THREADS), 0, c->stream, sp); };
     if (p.metric == ICP_METRIC_SYMMETRIC) {
         sp.phase = 0; sp.stats = nullptr; sp.sums_out = nullptr;
         reduce_solve();                                                                              // means
