@@ -24,7 +24,8 @@
 #define ICP_SEED_DESCENT 1
 #endif
 #ifndef ICP_COOP_MAX
-#define ICP_COOP_MAX 8          // a wave with at most this many (seeded) queries left to search does them cooperatively, one per lane group; 0 = never
+#define ICP_COOP_MAX 16         // a wave with at most this many (seeded) queries left to search does them cooperatively, one per lane group; 0 = never
+                                // (measured, iterations 10-16: 2 one after the other 0.0424 ms, 8 at once 0.0382, 16 at once 0.0334)
 #endif
 #ifndef ICP_PREFETCH_PATH
 #define ICP_PREFETCH_PATH 1
