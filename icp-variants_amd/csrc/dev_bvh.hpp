@@ -588,6 +588,9 @@ __device__ __forceinline__ void quad_pop_bits(QuadStateT<MaskT>& st) {
         st.idx = ((st.idx >> (2 * (st.L - lv))) << 2) | c; st.L = lv + 1; st.alive = true;
     }
 }
+#ifndef ICP_SORT_WALKS
+#define ICP_SORT_WALKS 0          // 1: the fused matcher re-assigns the queries of a block to its lanes by the length of their last walk
+#endif
 #ifndef ICP_DEBUG_STEPS
 #define ICP_DEBUG_STEPS 0        // 1: development build that records nodes + leaves visited per query (icp_debug_steps)
 #endif
@@ -599,7 +602,7 @@ __device__ int g_dbg_nodes_dummy;
 #endif
 template <int DIM, class MaskT>
 __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<DIM>& qp, QuadStateT<MaskT>& st,
-                                         float& best, int& bi, int& bpos, float& best2, float& minlb, int& dbg_nodes, int& dbg_leaves) {
+                                         float& best, int& bi, int& bpos, float& best2, float& minlb, int& dbg_nodes, int& dbg_leaves, int& steps) {
     const int Lq = bv.Lq;
     // A box is skipped when its lower bound exceeds thr = best * (1 + 2e-5) (clamped so that the +inf bound of an empty box is
     // always skipped): that implies bound > best with margin, one multiply per change of `best` instead of one per box test.
@@ -611,7 +614,7 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<
     while (st.alive) {
         while (st.alive && st.L < Lq) {
             f2 l01, l23;
-            ICP_COUNT_STEP(dbg_nodes);
+            ICP_COUNT_STEP(dbg_nodes); steps++;
             quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * st.L)) - 1u)) + (unsigned int)st.idx, qp, l01, l23);
             const float m = fminf(fminf(l01.x, l01.y), fminf(l23.x, l23.y));
             const bool s0 = !(l01.x > thr), s1 = !(l01.y > thr), s2 = !(l23.x > thr), s3 = !(l23.y > thr);
@@ -628,7 +631,7 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<
             quad_pop_bits(st);
         }
         if (st.alive) {
-            ICP_COUNT_STEP(dbg_leaves);
+            ICP_COUNT_STEP(dbg_leaves); steps++;
             leaf_eval<DIM>(bv.leaves + st.idx, st.idx, qp.p2, best, bi, bpos, best2);
             thr = fminf(best * 1.00002f, FLT_MAX);
             st.alive = false;
@@ -801,8 +804,8 @@ __device__ __forceinline__ bool coop_search(const BvhViewT<DIM>& bv, const float
 // The tree walk proper for query p, starting from the seed (best, bi, bpos); returns the lower bound on the distance to every
 // target other than the winner.  NT = threads of the block (layout of the LDS stacks).
 template <int DIM, int NT>
-__device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* p, float& best, int& bi, int& bpos, uint2* __restrict__ lbq, int tid, int* dbg_out = nullptr) {
-    int dbg_nodes = 0, dbg_leaves = 0;
+__device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* p, float& best, int& bi, int& bpos, uint2* __restrict__ lbq, int tid, int* dbg_out = nullptr, int* steps_out = nullptr) {
+    int dbg_nodes = 0, dbg_leaves = 0, steps = 0;         // steps: nodes + leaves visited (register; the fused matcher sorts its lanes by it)
     QueryPt<DIM> qp;
     make_query<DIM>(bv, p, qp);
     float best2 = FLT_MAX, minlb = FLT_MAX;
@@ -825,11 +828,12 @@ __device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* 
     if (ICP_PREFETCH_PATH && bpos >= 0) touched = quad_prefetch_path<DIM>(bv, bpos >> 3);
     if (bv.Lq <= 8) {                                     // uniform: up to 8 levels (524 288 targets) the pending bits fit 32 bits
         QuadStateT<unsigned int> st; st.L = 0; st.idx = 0; st.pending = 0u; st.alive = true;
-        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, minlb, dbg_nodes, dbg_leaves);
+        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, minlb, dbg_nodes, dbg_leaves, steps);
     } else {
         QuadStateT<unsigned long long> st; st.L = 0; st.idx = 0; st.pending = 0ull; st.alive = true;
-        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, minlb, dbg_nodes, dbg_leaves);
+        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, minlb, dbg_nodes, dbg_leaves, steps);
     }
+    if (steps_out) *steps_out = steps;
 #if ICP_DEBUG_STEPS
     if (dbg_out) *dbg_out = dbg_nodes | (dbg_leaves << 16);
 #endif

@@ -85,6 +85,7 @@ struct icp_ctx {
     DevBuf sel_lists, sel_counts, sel_blocks;            // RANDOM_SAMPLING: per-iteration index lists, their sizes, scan scratch
     DevBuf qstate;                                       // incremental k-NN: per-query position + bound on the other targets
     DevBuf dbg_steps;                    // development builds only (ICP_DEBUG_STEPS)
+    DevBuf qperm;                        // fused BVH matcher: lane assignment inside every block (ICP_SORT_WALKS)
     DevBuf ps, matches, d2, best64, nn_raw, partials, totals, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
     Cloud conv_src, conv_ref; int conv_n = 0;
     float cos_reject = 0.5f;
@@ -397,6 +398,11 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
         PostParams pp = make_post_params(c, *fuse, kp.sel, n);
         pp.matches = nullptr;                                                     // the loop never reads the records of a fused iteration
         KnnParams kf = kp; kf.d2_out = nullptr; kf.out = nullptr;                 // ... nor the distances
+#if ICP_SORT_WALKS
+        static_assert(BVH_THREADS <= 256, "lane assignment is kept in bytes");
+        if ((rc = ensure(c, c->qperm, (size_t)nb * BVH_THREADS))) return rc;
+        kf.qperm = c->qperm.as<unsigned char>();
+#endif
         const size_t red_bytes = (size_t)(BVH_THREADS / WAVE) * 33 * 8;           // the reduction reuses the (dead) traversal stacks
         hipLaunchKernelGGL(k_knn_bvh_post<DIM>, dim3(nb), dim3(BVH_THREADS), stack_bytes > red_bytes ? stack_bytes : red_bytes, c->stream, kf, bv, order, pp);
         *fused_blocks = nb;
@@ -432,7 +438,7 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr) {
     kp.tx = c->tgt.x.as<float>(); kp.ty = c->tgt.y.as<float>(); kp.tz = c->tgt.z.as<float>();
     kp.tcr = c->tgt.cr.as<float>(); kp.tcg = c->tgt.cg.as<float>(); kp.tcb = c->tgt.cb.as<float>();
     kp.mpad = c->tgt.npad; kp.ps = c->ps.as<PoseState>(); kp.pretransformed = q.pretransformed; kp.max_dist = p.max_distance;
-    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0; kp.qstate = nullptr; kp.incremental = 0; kp.dbg_steps = nullptr;
+    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0; kp.qstate = nullptr; kp.incremental = 0; kp.dbg_steps = nullptr; kp.qperm = nullptr;
     if (p.knn_backend == ICP_KNN_LBVH) {
         kp.nseg = 1;
         if ((rc = ensure(c, c->nn_raw, (size_t)q.n * 4))) return rc;
@@ -652,7 +658,7 @@ int icp_ctx_destroy(icp_ctx* c) {
     for (Bvh* b : {&c->bvh6, &c->nrm_bvh}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
     release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) release(kv.second);
-    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->dbg_steps); release(c->sums);
+    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->dbg_steps); release(c->qperm); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
     for (DevBuf* d : {&c->src_flag, &c->src_box, &c->tgt_flag, &c->tgt_finite, &c->nrm_finite, &c->sel_temp, &c->d_count}) release(*d);
     if (c->pin_up) (void)hipHostFree(c->pin_up);
