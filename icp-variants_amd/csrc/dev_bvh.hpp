@@ -166,6 +166,61 @@ __global__ void k_bvh_level_keys(const CoordPtrs<DIM> cp, const int* __restrict_
     keys[i] = ((unsigned long long)(unsigned int)node << 32) | ordered_bits(c);
 }
 
+// ---- upper levels from PRESORTED axes ---------------------------------------------------------------------------------------
+// Round 1 re-sorted the whole array once per upper level (key = node id | coordinate along the node's widest axis: one global sort
+// of ~120 us per level, 8 levels).  The classic kd-tree construction needs each axis sorted only ONCE: keep one index list per axis,
+// all of them grouped by node; per level every node reads its box from the ends of its segments (first / last element of each
+// axis list), picks the widest axis, declares the first half of THAT list its left child, and every list is stably partitioned by
+// that left / right flag (exclusive scan of the flags + scatter) so that it stays sorted inside both children.  DIM sorts of
+// 32-bit keys once, then per level DIM x (scan + scatter) -- and the result is the same kind of tree (median split by count along
+// the widest axis; ties now keep index order).
+template <int DIM> struct AxisLists { const int* L[DIM]; };
+__global__ void k_axis_keys(const float* __restrict__ plane, const int* __restrict__ ids, int nv, unsigned int* __restrict__ keys) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nv) keys[t] = ordered_bits(plane[ids[t]]);
+}
+template <int DIM>
+__global__ void k_presort_axis(const CoordPtrs<DIM> cp, const AxisLists<DIM> al, int nv, int seg_shift, int n_nodes, unsigned char* __restrict__ axis_of_node) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const long long start = (long long)i << seg_shift;
+    int axis = 0;
+    if (start < nv) {
+        const int end = (int)min((long long)nv, start + (1ll << seg_shift));
+        float ext = -1.f;
+#pragma unroll
+        for (int k = 0; k < DIM; k++) {
+            const float e = cp.c[k][al.L[k][end - 1]] - cp.c[k][al.L[k][(int)start]];
+            if (e > ext) { ext = e; axis = k; }
+        }
+    }
+    axis_of_node[i] = (unsigned char)axis;
+}
+template <int DIM>
+__global__ void k_presort_side(const AxisLists<DIM> al, int nv, int seg_shift, const unsigned char* __restrict__ axis_of_node, unsigned char* __restrict__ side /* by point id */) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nv) return;
+    const int i = t >> seg_shift, a = axis_of_node[i];
+    int j = al.L[0][t];
+#pragma unroll
+    for (int k = 1; k < DIM; k++) { const int jk = al.L[k][t]; j = (a == k) ? jk : j; }      // (values selected, not pointers: see k_bvh_block_levels)
+    side[j] = ((t - (i << seg_shift)) >= (1 << (seg_shift - 1))) ? 1 : 0;
+}
+struct SideOfEntry {                                      // flag of the point at position t of one axis list (input of the scan)
+    const unsigned char* side; const int* L;
+    __host__ __device__ int operator()(int t) const { return (int)side[L[t]]; }
+};
+__global__ void k_presort_scatter(const int* __restrict__ Lk, const unsigned char* __restrict__ side, const int* __restrict__ R /* exclusive scan of the flags in list order */,
+                                  int nv, int seg_shift, int* __restrict__ Lk_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nv) return;
+    const int j = Lk[t];
+    const int S = (t >> seg_shift) << seg_shift;
+    const int cnt = min(1 << seg_shift, nv - S), nleft = min(1 << (seg_shift - 1), cnt);
+    const int r_before = R[t] - R[S];
+    Lk_out[side[j] ? S + nleft + r_before : S + (t - S - r_before)] = j;
+}
+
 // The lower levels of the build in one kernel.  Once a node's slice is <= 2048 points the remaining levels only permute
 // points INSIDE that slice, so a block takes 2048 consecutive positions into LDS and runs all of them there: per level the
 // boxes of the slices (shuffle tree + at most 4 wave boxes), the widest axis, and a bitonic sort of every slice on
@@ -588,9 +643,6 @@ __device__ __forceinline__ void quad_pop_bits(QuadStateT<MaskT>& st) {
         st.idx = ((st.idx >> (2 * (st.L - lv))) << 2) | c; st.L = lv + 1; st.alive = true;
     }
 }
-#ifndef ICP_SORT_WALKS
-#define ICP_SORT_WALKS 0          // 1: the fused matcher re-assigns the queries of a block to its lanes by the length of their last walk
-#endif
 #ifndef ICP_DEBUG_STEPS
 #define ICP_DEBUG_STEPS 0        // 1: development build that records nodes + leaves visited per query (icp_debug_steps)
 #endif
@@ -602,7 +654,7 @@ __device__ int g_dbg_nodes_dummy;
 #endif
 template <int DIM, class MaskT>
 __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<DIM>& qp, QuadStateT<MaskT>& st,
-                                         float& best, int& bi, int& bpos, float& best2, float& minlb, int& dbg_nodes, int& dbg_leaves, int& steps) {
+                                         float& best, int& bi, int& bpos, float& best2, float& minlb, int& dbg_nodes, int& dbg_leaves) {
     const int Lq = bv.Lq;
     // A box is skipped when its lower bound exceeds thr = best * (1 + 2e-5) (clamped so that the +inf bound of an empty box is
     // always skipped): that implies bound > best with margin, one multiply per change of `best` instead of one per box test.
@@ -614,7 +666,7 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<
     while (st.alive) {
         while (st.alive && st.L < Lq) {
             f2 l01, l23;
-            ICP_COUNT_STEP(dbg_nodes); steps++;
+            ICP_COUNT_STEP(dbg_nodes);
             quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * st.L)) - 1u)) + (unsigned int)st.idx, qp, l01, l23);
             const float m = fminf(fminf(l01.x, l01.y), fminf(l23.x, l23.y));
             const bool s0 = !(l01.x > thr), s1 = !(l01.y > thr), s2 = !(l23.x > thr), s3 = !(l23.y > thr);
@@ -631,7 +683,7 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<
             quad_pop_bits(st);
         }
         if (st.alive) {
-            ICP_COUNT_STEP(dbg_leaves); steps++;
+            ICP_COUNT_STEP(dbg_leaves);
             leaf_eval<DIM>(bv.leaves + st.idx, st.idx, qp.p2, best, bi, bpos, best2);
             thr = fminf(best * 1.00002f, FLT_MAX);
             st.alive = false;
@@ -804,8 +856,8 @@ __device__ __forceinline__ bool coop_search(const BvhViewT<DIM>& bv, const float
 // The tree walk proper for query p, starting from the seed (best, bi, bpos); returns the lower bound on the distance to every
 // target other than the winner.  NT = threads of the block (layout of the LDS stacks).
 template <int DIM, int NT>
-__device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* p, float& best, int& bi, int& bpos, uint2* __restrict__ lbq, int tid, int* dbg_out = nullptr, int* steps_out = nullptr) {
-    int dbg_nodes = 0, dbg_leaves = 0, steps = 0;         // steps: nodes + leaves visited (register; the fused matcher sorts its lanes by it)
+__device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* p, float& best, int& bi, int& bpos, uint2* __restrict__ lbq, int tid, int* dbg_out = nullptr) {
+    int dbg_nodes = 0, dbg_leaves = 0;
     QueryPt<DIM> qp;
     make_query<DIM>(bv, p, qp);
     float best2 = FLT_MAX, minlb = FLT_MAX;
@@ -828,12 +880,11 @@ __device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* 
     if (ICP_PREFETCH_PATH && bpos >= 0) touched = quad_prefetch_path<DIM>(bv, bpos >> 3);
     if (bv.Lq <= 8) {                                     // uniform: up to 8 levels (524 288 targets) the pending bits fit 32 bits
         QuadStateT<unsigned int> st; st.L = 0; st.idx = 0; st.pending = 0u; st.alive = true;
-        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, minlb, dbg_nodes, dbg_leaves, steps);
+        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, minlb, dbg_nodes, dbg_leaves);
     } else {
         QuadStateT<unsigned long long> st; st.L = 0; st.idx = 0; st.pending = 0ull; st.alive = true;
-        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, minlb, dbg_nodes, dbg_leaves, steps);
+        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, minlb, dbg_nodes, dbg_leaves);
     }
-    if (steps_out) *steps_out = steps;
 #if ICP_DEBUG_STEPS
     if (dbg_out) *dbg_out = dbg_nodes | (dbg_leaves << 16);
 #endif

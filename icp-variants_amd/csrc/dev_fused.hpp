@@ -28,7 +28,10 @@ struct P2pGen {                                           // values 0..21 = sum 
 // Measured and NOT adopted (round 2): folding the block partials and solving INSIDE this launch (two levels of "last arriver
 // folds", write-through hand-over without fences).  Correct (the whole GPU suite passed with it) but slower: every level is three
 // dependent trips to memory (publish, ticket, fold) at ~1.5 us each, the tail of the launch grew by ~20 us against ~12 us for the
-// separate k_reduce_solve launch (17.3 k vs 20.0 k iterations/s).  What did pay was making k_reduce_solve itself cheaper (one load
+// separate k_reduce_solve launch (17.3 k vs 20.0 k iterations/s).  Also measured and dropped: handing the queries of a block to its lanes
+// in the order of their last walk's length (waves of like lengths, walker-free waves once many verify; one byte of assignment per
+// query, a stable 8-class rank in the epilogue): iterations 1-9 0.084 vs 0.079 ms -- the prediction is not worth the extra dependent
+// load in front of everything and the gathers.  What did pay was making k_reduce_solve itself cheaper (one load
 // round, fence-free hand-over): see dev_solve.hpp.
 template <int DIM>
 __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {
@@ -36,17 +39,8 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
     constexpr int NW = BVH_THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int t0 = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS;
-    int off = tid;                                        // which query of the block's BVH_THREADS this lane serves
-#if ICP_SORT_WALKS
-    // Lanes of a wave wait for the longest walk among them, and walk lengths repeat from one ICP iteration to the next.  Every launch
-    // ends by ranking the block's queries by the length of the walk they just needed (verified: none) and the next launch hands them
-    // to its lanes in that order: waves of like lengths -- and, once many queries verify, waves with no walker at all.  The
-    // assignment changes who computes, never what: results, partial-sum slots and state stay indexed by the query.
-    if (kp.qperm && kp.use_prev) off = kp.qperm[t0 + tid];
-#endif
-    const int t = t0 + off;
+    const int t = t0 + tid;
     const int k = (t < kp.n) ? (qorder ? qorder[t] : t) : -1;
-    int walk_steps = 0;
     bool valid = false;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, wt = 0.f;
     float p[DIM];
@@ -123,7 +117,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
 #if ICP_DEBUG_STEPS
     if (k >= 0 && kp.dbg_steps) kp.dbg_steps[k] = need_walk ? -1 : 0;      // -1: a cooperative search took it (overwritten by a per-lane walk)
 #endif
-    if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, bvh_lbq, tid, (ICP_DEBUG_STEPS && kp.dbg_steps) ? kp.dbg_steps + k : nullptr, &walk_steps);
+    if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, bvh_lbq, tid, (ICP_DEBUG_STEPS && kp.dbg_steps) ? kp.dbg_steps + k : nullptr);
     if (k >= 0) {
         // A verified query keeps its stored anchor (position of the last full search) and bound: the triangle test stays valid
         // against the OLD anchor -- and is tighter than re-anchoring, (L - d1) - d2 <= L - |d1 + d2| -- and its neighbour is
@@ -176,37 +170,4 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
         }
         pp.partials[(size_t)tid * nb + lb] = out;
     }
-#if ICP_SORT_WALKS
-    if (kp.qperm) {
-        // class of this launch's walk: 0 = none (verified, cooperative, invalid), 1..7 by length; stable rank over the block
-        __shared__ unsigned int s_cnt[NW][8];
-        const int key = walk_steps == 0 ? 0 : walk_steps <= 12 ? 1 : walk_steps <= 16 ? 2 : walk_steps <= 20 ? 3 : walk_steps <= 25 ? 4 : walk_steps <= 31 ? 5 : walk_steps <= 40 ? 6 : 7;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        int below_in_wave = 0, eq_lower = 0; unsigned int mycnt = 0u;
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const unsigned long long mc = __ballot(key == c);
-            const int n = __popcll(mc);
-            if (c < key) below_in_wave += n;
-            if (c == key) eq_lower = __popcll(mc & lt);
-            if (lane == c) mycnt = (unsigned int)n;
-        }
-        if (lane < 8) s_cnt[w][lane] = mycnt;
-        __syncthreads();
-        int walkers = 0, rank = 0;
-#pragma unroll
-        for (int ww = 0; ww < NW; ww++) {
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const int n = (int)s_cnt[ww][c];
-                if (c > 0) walkers += n;
-                if (c < key || (c == key && ww < w)) rank += n;
-            }
-        }
-        rank += eq_lower;
-        // few walkers: leave them spread over the waves (each wave then searches its handful cooperatively, all at once)
-        if (walkers > 2 * ICP_COOP_MAX) kp.qperm[t0 + rank] = (unsigned char)off;
-        else kp.qperm[t0 + off] = (unsigned char)off;
-    }
-#endif
 }

@@ -27,7 +27,6 @@ struct KnnParams {
     int use_prev;                                            // 1: nn_raw holds the previous iteration's result for the same queries
     float4* qstate;                                          // [n] (query xyz when last searched or verified, lower bound on the distance to every OTHER target)
     int incremental;                                         // 1: verify-and-skip with qstate (needs use_prev)
-    unsigned char* qperm;                                    // fused BVH matcher: [blocks * BVH_THREADS] which query offset each lane of a block serves (written every launch, read when use_prev); nullptr = identity
     int* dbg_steps;                                          // development builds (ICP_DEBUG_STEPS): [n] nodes | leaves << 16 visited by the walk of query k; nullptr otherwise
 };
 

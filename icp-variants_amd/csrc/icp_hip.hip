@@ -11,6 +11,7 @@
 #include "icp_device.hpp"
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 #include <cstdio>
@@ -55,6 +56,8 @@ struct Bvh {
     bool valid = false;
     int n_valid = 0, n_leaves = 0, Lp = 1;
     DevBuf keys, keys2, vals, vals2, temp, leaves, recs, nodes, qnodes, qq, grid, lvl, wbox;
+    DevBuf axl[12], side, scanr, axis_of_node;      // presorted-axes build: DIM index lists (ping-pong), side flag per point id, scan result, widest axis per node
+    int n_ids = 0;                                   // size of the id space the lists index (points of the cloud the tree is built over)
     const Cloud* attrs = nullptr;                     // cloud whose normals / colours go into the records (nullptr: none)
     int Lq = 0;                                       // 4-wide levels
     const int* d_finite = nullptr;                    // device list of the finite points' indices, increasing (owned by the context)
@@ -71,6 +74,7 @@ struct icp_ctx {
     unsigned timing_phase = 0;           // rotates the sampled iterations from run to run
     void* pinned = nullptr; size_t pinned_cap = 0;   // page-locked host staging: pose upload, stats + pose download (truly asynchronous copies)
     bool block_levels = true;            // BVH build: levels with slices <= 2048 points in one LDS kernel (ICP_HIP_BLOCK_LEVELS=0: global sorts)
+    bool presort = true;                 // BVH build: upper levels from presorted axes (ICP_HIP_PRESORT=0: one global sort per level)
     bool trace = false;                  // ICP_HIP_TRACE=1: per-iteration stage times on stderr
     bool fuse_post = true;               // BVH matcher runs weight / reject / accumulate as its epilogue (ICP_HIP_FUSE_POST=0 disables)
     icp_params prm;
@@ -85,7 +89,6 @@ struct icp_ctx {
     DevBuf sel_lists, sel_counts, sel_blocks;            // RANDOM_SAMPLING: per-iteration index lists, their sizes, scan scratch
     DevBuf qstate;                                       // incremental k-NN: per-query position + bound on the other targets
     DevBuf dbg_steps;                    // development builds only (ICP_DEBUG_STEPS)
-    DevBuf qperm;                        // fused BVH matcher: lane assignment inside every block (ICP_SORT_WALKS)
     DevBuf ps, matches, d2, best64, nn_raw, partials, totals, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
     Cloud conv_src, conv_ref; int conv_n = 0;
     float cos_reject = 0.5f;
@@ -307,7 +310,49 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
         HIPCK(c, rocprim::radix_sort_pairs(nullptr, temp_bytes, b.keys.as<unsigned long long>(), b.keys2.as<unsigned long long>(), perm, perm2, (size_t)nv, 0, 64, c->stream));
         if ((rc = ensure(c, b.temp, temp_bytes))) return rc;
         const int gb = (nv + 255) / 256;
-        for (int d = 0; d < depth; d++) {
+        int d_first = 0;
+        if (c->presort && c->block_levels) {
+            // upper levels (slices > 2048 points) from presorted axes: see dev_bvh.hpp
+            int n_upper = 0;
+            for (int d = 0; d < depth; d++) { int sh = 0; { long long seg = (long long)BVH_LEAF * b.Lp >> d; while ((1LL << sh) < seg) sh++; } if (sh <= 11) break; n_upper++; }
+            if (n_upper > 0) {
+                for (int k = 0; k < 2 * DIM; k++) if ((rc = ensure(c, b.axl[k], (size_t)cap * 4))) return rc;
+                if ((rc = ensure(c, b.side, (size_t)(b.n_ids > 0 ? b.n_ids : 1)))) return rc;
+                if ((rc = ensure(c, b.scanr, (size_t)cap * 4))) return rc;
+                if ((rc = ensure(c, b.axis_of_node, (size_t)1 << n_upper))) return rc;
+                unsigned int* k32 = b.keys.as<unsigned int>(); unsigned int* k32b = b.keys2.as<unsigned int>();
+                size_t tb = 0, tb2 = 0;
+                HIPCK(c, rocprim::radix_sort_pairs(nullptr, tb, k32, k32b, perm, perm2, (size_t)nv, 0, 32, c->stream));
+                SideOfEntry probe{b.side.as<unsigned char>(), b.axl[0].as<int>()};
+                auto in0 = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), probe);
+                HIPCK(c, rocprim::exclusive_scan(nullptr, tb2, in0, b.scanr.as<int>(), 0, (size_t)nv, rocprim::plus<int>(), c->stream));
+                if ((rc = ensure(c, b.temp, tb > tb2 ? (tb > temp_bytes ? tb : temp_bytes) : (tb2 > temp_bytes ? tb2 : temp_bytes)))) return rc;
+                int* cur[DIM]; int* alt[DIM];
+                for (int k = 0; k < DIM; k++) {           // one stable sort per axis (ids arrive in increasing order: ties keep index order)
+                    cur[k] = b.axl[k].as<int>(); alt[k] = b.axl[DIM + k].as<int>();
+                    hipLaunchKernelGGL(k_axis_keys, dim3(gb), dim3(256), 0, c->stream, cp.c[k], b.d_finite, nv, k32);
+                    HIPCK(c, rocprim::radix_sort_pairs(b.temp.p, tb, k32, k32b, b.d_finite, cur[k], (size_t)nv, 0, 32, c->stream));
+                }
+                for (int d = 0; d < n_upper; d++) {
+                    int sh = 0; { long long seg = (long long)BVH_LEAF * b.Lp >> d; while ((1LL << sh) < seg) sh++; }
+                    AxisLists<DIM> al; for (int k = 0; k < DIM; k++) al.L[k] = cur[k];
+                    const int n_nodes = 1 << d;
+                    hipLaunchKernelGGL(k_presort_axis<DIM>, dim3((n_nodes + 255) / 256), dim3(256), 0, c->stream, cp, al, nv, sh, n_nodes, b.axis_of_node.as<unsigned char>());
+                    hipLaunchKernelGGL(k_presort_side<DIM>, dim3(gb), dim3(256), 0, c->stream, al, nv, sh, b.axis_of_node.as<unsigned char>(), b.side.as<unsigned char>());
+                    for (int k = 0; k < DIM; k++) {
+                        SideOfEntry fn{b.side.as<unsigned char>(), cur[k]};
+                        auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), fn);
+                        HIPCK(c, rocprim::exclusive_scan(b.temp.p, tb2, in, b.scanr.as<int>(), 0, (size_t)nv, rocprim::plus<int>(), c->stream));
+                        hipLaunchKernelGGL(k_presort_scatter, dim3(gb), dim3(256), 0, c->stream, cur[k], b.side.as<unsigned char>(), b.scanr.as<int>(), nv, sh, alt[k]);
+                        int* t = cur[k]; cur[k] = alt[k]; alt[k] = t;
+                    }
+                }
+                HIPCK(c, hipMemcpyAsync(perm, cur[0], (size_t)nv * 4, hipMemcpyDeviceToDevice, c->stream));      // any list: the block kernel sorts inside its slices
+                HIPCK(c, hipGetLastError());
+                d_first = n_upper;
+            }
+        }
+        for (int d = d_first; d < depth; d++) {
             // segment (node) size at level d in points: BVH_LEAF * Lp / 2^d  = 1 << seg_shift
             int seg_shift = 0; { long long seg = (long long)BVH_LEAF * b.Lp >> d; while ((1LL << seg_shift) < seg) seg_shift++; }
             if (c->block_levels && seg_shift <= 11) {        // slices of <= 2048 points: all remaining levels inside LDS, one launch
@@ -398,11 +443,6 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
         PostParams pp = make_post_params(c, *fuse, kp.sel, n);
         pp.matches = nullptr;                                                     // the loop never reads the records of a fused iteration
         KnnParams kf = kp; kf.d2_out = nullptr; kf.out = nullptr;                 // ... nor the distances
-#if ICP_SORT_WALKS
-        static_assert(BVH_THREADS <= 256, "lane assignment is kept in bytes");
-        if ((rc = ensure(c, c->qperm, (size_t)nb * BVH_THREADS))) return rc;
-        kf.qperm = c->qperm.as<unsigned char>();
-#endif
         const size_t red_bytes = (size_t)(BVH_THREADS / WAVE) * 33 * 8;           // the reduction reuses the (dead) traversal stacks
         hipLaunchKernelGGL(k_knn_bvh_post<DIM>, dim3(nb), dim3(BVH_THREADS), stack_bytes > red_bytes ? stack_bytes : red_bytes, c->stream, kf, bv, order, pp);
         *fused_blocks = nb;
@@ -438,7 +478,7 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr) {
     kp.tx = c->tgt.x.as<float>(); kp.ty = c->tgt.y.as<float>(); kp.tz = c->tgt.z.as<float>();
     kp.tcr = c->tgt.cr.as<float>(); kp.tcg = c->tgt.cg.as<float>(); kp.tcb = c->tgt.cb.as<float>();
     kp.mpad = c->tgt.npad; kp.ps = c->ps.as<PoseState>(); kp.pretransformed = q.pretransformed; kp.max_dist = p.max_distance;
-    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0; kp.qstate = nullptr; kp.incremental = 0; kp.dbg_steps = nullptr; kp.qperm = nullptr;
+    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0; kp.qstate = nullptr; kp.incremental = 0; kp.dbg_steps = nullptr;
     if (p.knn_backend == ICP_KNN_LBVH) {
         kp.nseg = 1;
         if ((rc = ensure(c, c->nn_raw, (size_t)q.n * 4))) return rc;
@@ -630,6 +670,7 @@ int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out) {
     memset(&c->timing, 0, sizeof(c->timing));
     if (hipSetDevice(device) != hipSuccess) { delete c; return ICP_ERR_HIP; }
     { const char* e = getenv("ICP_HIP_FUSE_POST"); if (e && e[0] == '0') c->fuse_post = false; }
+    { const char* e = getenv("ICP_HIP_PRESORT"); if (e && e[0] == '0') c->presort = false; }
     { const char* e = getenv("ICP_HIP_BLOCK_LEVELS"); if (e && e[0] == '0') c->block_levels = false; }
     { const char* e = getenv("ICP_HIP_TRACE"); if (e && e[0] == '1') c->trace = true; }
     { const char* e = getenv("ICP_HIP_STAGE_EVENTS"); if (e && e[0] >= '0' && e[0] <= '9') c->stage_timing = atoi(e); }
@@ -654,11 +695,11 @@ int icp_ctx_destroy(icp_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release(c->tgt); release(c->src); release(c->qry); release(c->conv_src); release(c->conv_ref);
     release(c->nrm_cloud);
-    for (Bvh* b : {&c->bvh, &c->bvh6, &c->nrm_bvh}) { release(b->qnodes); release(b->recs); release(b->qq); release(b->grid); }
+    for (Bvh* b : {&c->bvh, &c->bvh6, &c->nrm_bvh}) { release(b->qnodes); release(b->recs); release(b->qq); release(b->grid); for (DevBuf& d : b->axl) release(d); release(b->side); release(b->scanr); release(b->axis_of_node); }
     for (Bvh* b : {&c->bvh6, &c->nrm_bvh}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
     release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) release(kv.second);
-    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->dbg_steps); release(c->qperm); release(c->sums);
+    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->dbg_steps); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
     for (DevBuf* d : {&c->src_flag, &c->src_box, &c->tgt_flag, &c->tgt_finite, &c->nrm_finite, &c->sel_temp, &c->d_count}) release(*d);
     if (c->pin_up) (void)hipHostFree(c->pin_up);
@@ -696,8 +737,8 @@ int icp_set_target(icp_ctx* c, const float* xyz, const float* normals, const uin
     b.valid = false; b.n_valid = 0;
     // non-finite targets can never win the strict-< argmin: they stay out of the tree (filter + compaction on the device)
     if ((rc = finite_list(c, c->tgt, false, c->tgt_flag, c->tgt_finite, &b.n_valid))) return rc;
-    b.d_finite = c->tgt_finite.as<int>();
-    c->bvh6.d_finite = b.d_finite; c->bvh6.n_valid = b.n_valid;
+    b.d_finite = c->tgt_finite.as<int>(); b.n_ids = n;
+    c->bvh6.d_finite = b.d_finite; c->bvh6.n_valid = b.n_valid; c->bvh6.n_ids = n;
     b.attrs = &c->tgt; c->bvh6.attrs = &c->tgt;
     if (c->prm.knn_backend == ICP_KNN_LBVH && c->prm.matching == ICP_MATCH_KNN) {                         // buildIndex; otherwise built on first use
         if (c->prm.color_icp && rgba) return guard.done(build_bvh<6>(c, c->bvh6, target_coords6(c)));
@@ -1085,7 +1126,7 @@ int icp_estimate_normals(icp_ctx* c, const float* xyz, int32_t n, int32_t k, con
     if ((rc = upload_cloud(c, cl, xyz, nullptr, nullptr, n, false))) return rc;
     b.valid = false;
     if ((rc = finite_list(c, cl, false, c->tgt_flag, c->nrm_finite, &b.n_valid))) return rc;      // (tgt_flag is scratch here: only its list is kept)
-    b.d_finite = c->nrm_finite.as<int>();
+    b.d_finite = c->nrm_finite.as<int>(); b.n_ids = n;
     CoordPtrs<3> cp; cp.c[0] = cl.x.as<float>(); cp.c[1] = cl.y.as<float>(); cp.c[2] = cl.z.as<float>();
     if ((rc = build_bvh<3>(c, b, cp))) return rc;
     BvhViewT<3> bv; bv.leaves = b.leaves.as<BvhLeafT<3>>(); bv.nodes = b.nodes.as<BvhNodeT<3>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
