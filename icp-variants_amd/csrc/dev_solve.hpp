@@ -235,6 +235,7 @@ struct SolveParams {
     double* sums_out;              // optional copy of the reduced sums (NSUM doubles)
     int update_pose;               // 0: only reduce (icp_correspond)
     const double* rmse_partials; int rmse_blocks;   // unused here
+    int spin;                      // 1: block 0 waits for the other blocks' totals (self-validating 8-byte values) instead of the ticket hand-over
 };
 
 // Point-to-plane fast path of k_reduce_solve on the lanes of the (last) block instead of one thread: the same LDL^T recurrences
@@ -419,6 +420,8 @@ __device__ __forceinline__ void solve_tail(const SolveParams& sp, const double* 
 // then the waves in order) -- identical on every run and independent of block scheduling.  The block that finishes last (ticket
 // counter, release/acquire fences at agent scope) gathers the NSUM totals and runs the small fp64 solve + pose composition.
 constexpr int SOLVE_THREADS = 256;
+constexpr unsigned long long TOTAL_SENTINEL = 0xFFF8D1CEC0DE5EEDull;      // a NaN payload no arithmetic produces: "total not written yet"
+constexpr int SPIN_LIMIT = 1 << 16;
 constexpr int SOLVE_INFLIGHT = 12;                        // loads in flight per thread: 12 x 256 = 3072 partials in ONE memory round trip
 __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParams sp) {
     __shared__ double tot[NSUM];
@@ -442,6 +445,40 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
         if (lane == 0) wsum[w] = x;
     }
     __syncthreads();
+    if (sp.spin) {
+        // Hand-over without a ticket: every total is ONE naturally aligned 8-byte write-through store and validates itself (anything
+        // but the sentinel the slots hold between launches), so nothing has to be ordered against anything: block 0 -- always
+        // resident, like the other 33 -- polls the 34 slots with sc1 loads, one lane per slot, takes the values, puts the sentinels
+        // back and solves.  Against store -> drain -> ticket -> re-load that is two dependent trips to memory less per launch.  The
+        // wait is bounded: after SPIN_LIMIT polls (~ tens of ms) a slot is taken as it is -- a total that happens to BE the sentinel
+        // bit pattern (a NaN with that payload) cannot hang the launch.
+        if (threadIdx.x == 0) {
+            double x = wsum[0];
+            for (int k = 1; k < SOLVE_THREADS / WAVE; k++) x += wsum[k];
+            unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+            if (bits == TOTAL_SENTINEL) bits ^= 1ull;         // (still a NaN: the solve's result is the same)
+            __hip_atomic_store((unsigned long long*)sp.totals + a, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (a != 0) return;
+        if (threadIdx.x < NSUM) {
+            double v = 0.0;
+            if (threadIdx.x < NSUM_USED) {
+                unsigned long long* slot = (unsigned long long*)sp.totals + threadIdx.x;
+                unsigned long long bits = TOTAL_SENTINEL;
+                for (int spin = 0; spin < SPIN_LIMIT; spin++) {
+                    bits = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (bits != TOTAL_SENTINEL) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                v = __longlong_as_double((long long)bits);
+                __hip_atomic_store(slot, TOTAL_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            }
+            tot[threadIdx.x] = v;
+        }
+        __syncthreads();
+        solve_tail(sp, tot);
+        return;
+    }
     if (threadIdx.x == 0) {
         double x = wsum[0];
         for (int k = 1; k < SOLVE_THREADS / WAVE; k++) x += wsum[k];

@@ -74,6 +74,7 @@ struct icp_ctx {
     unsigned timing_phase = 0;           // rotates the sampled iterations from run to run
     void* pinned = nullptr; size_t pinned_cap = 0;   // page-locked host staging: pose upload, stats + pose download (truly asynchronous copies)
     bool block_levels = true;            // BVH build: levels with slices <= 2048 points in one LDS kernel (ICP_HIP_BLOCK_LEVELS=0: global sorts)
+    bool spin_reduce = false;            // k_reduce_solve: block 0 polls the self-validating totals (ICP_HIP_SPIN_REDUCE=1) instead of the ticket hand-over
     bool presort = true;                 // BVH build: upper levels from presorted axes (ICP_HIP_PRESORT=0: one global sort per level)
     bool trace = false;                  // ICP_HIP_TRACE=1: per-iteration stage times on stderr
     bool fuse_post = true;               // BVH matcher runs weight / reject / accumulate as its epilogue (ICP_HIP_FUSE_POST=0 disables)
@@ -524,6 +525,7 @@ int launch_post_and_solve(icp_ctx* c, const Cloud& src, const int* sel, int n, i
     if (!c->totals.p) {                                     // NSUM totals + the arrival counter of the reduce/solve kernel
         if ((rc = ensure(c, c->totals, NSUM * 8 + 8))) return rc;
         HIPCK(c, hipMemsetAsync(c->totals.p, 0, NSUM * 8 + 8, c->stream));
+        if (c->spin_reduce) hipLaunchKernelGGL(k_fill_u64, dim3(1), dim3(64), 0, c->stream, c->totals.as<unsigned long long>(), NSUM, TOTAL_SENTINEL);
     }
     const PostParams pp = make_post_params(c, src, sel, n);
     int nb = (n + POST_THREADS - 1) / POST_THREADS; if (nb > POST_BLOCKS) nb = POST_BLOCKS; if (nb < 1) nb = 1;
@@ -532,7 +534,7 @@ int launch_post_and_solve(icp_ctx* c, const Cloud& src, const int* sel, int n, i
     SolveParams sp; memset(&sp, 0, sizeof(sp));
     sp.partials = c->partials.as<double>(); sp.nblocks = nb; sp.ps = c->ps.as<PoseState>(); sp.metric = p.metric;
     sp.totals = c->totals.as<double>(); sp.ticket = (unsigned*)(c->totals.as<double>() + NSUM);
-    sp.n_src = n; sp.update_pose = update_pose;
+    sp.n_src = n; sp.update_pose = update_pose; sp.spin = c->spin_reduce ? 1 : 0;
     auto reduce_solve = [&]() { hipLaunchKernelGGL(k_reduce_solve, dim3(NSUM_USED), dim3(SOLVE_THREADS), 0, c->stream, sp); };
     if (p.metric == ICP_METRIC_SYMMETRIC) {
         sp.phase = 0; sp.stats = nullptr; sp.sums_out = nullptr;
@@ -670,6 +672,7 @@ int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out) {
     memset(&c->timing, 0, sizeof(c->timing));
     if (hipSetDevice(device) != hipSuccess) { delete c; return ICP_ERR_HIP; }
     { const char* e = getenv("ICP_HIP_FUSE_POST"); if (e && e[0] == '0') c->fuse_post = false; }
+    { const char* e = getenv("ICP_HIP_SPIN_REDUCE"); if (e) c->spin_reduce = e[0] == '1'; }
     { const char* e = getenv("ICP_HIP_PRESORT"); if (e && e[0] == '0') c->presort = false; }
     { const char* e = getenv("ICP_HIP_BLOCK_LEVELS"); if (e && e[0] == '0') c->block_levels = false; }
     { const char* e = getenv("ICP_HIP_TRACE"); if (e && e[0] == '1') c->trace = true; }
