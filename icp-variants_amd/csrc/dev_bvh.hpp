@@ -206,19 +206,64 @@ __global__ void k_presort_side(const AxisLists<DIM> al, int nv, int seg_shift, c
     for (int k = 1; k < DIM; k++) { const int jk = al.L[k][t]; j = (a == k) ? jk : j; }      // (values selected, not pointers: see k_bvh_block_levels)
     side[j] = ((t - (i << seg_shift)) >= (1 << (seg_shift - 1))) ? 1 : 0;
 }
-struct SideOfEntry {                                      // flag of the point at position t of one axis list (input of the scan)
-    const unsigned char* side; const int* L;
-    __host__ __device__ int operator()(int t) const { return (int)side[L[t]]; }
-};
-__global__ void k_presort_scatter(const int* __restrict__ Lk, const unsigned char* __restrict__ side, const int* __restrict__ R /* exclusive scan of the flags in list order */,
-                                  int nv, int seg_shift, int* __restrict__ Lk_out) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// The stable partition of all DIM lists of one level in three launches (grid.y = axis): per 256-position block the number of
+// right-child entries, an exclusive scan of those block counts (one block per list), and the scatter that recomputes its block's
+// flags, ranks them with ballots and adds the block and segment offsets.  (A library scan per list cost two launches and ~12 us
+// each, three lists and eight levels: more than the sorts it replaced were worth.)  Segments are multiples of 4096 positions, so a
+// segment always starts on a block boundary: the number of right entries before it is a block offset.
+constexpr int PRS_THREADS = 256;
+template <int DIM>
+__global__ __launch_bounds__(PRS_THREADS) void k_presort_count(const AxisLists<DIM> al, const unsigned char* __restrict__ side, int nv, int* __restrict__ blk_cnt /* [DIM][nblk] */) {
+    __shared__ int wc[PRS_THREADS / WAVE];
+    const int k = blockIdx.y, t = blockIdx.x * PRS_THREADS + threadIdx.x;
+    int j = 0;
+#pragma unroll
+    for (int q = 0; q < DIM; q++) { if (q == k) j = t < nv ? al.L[q][t] : 0; }       // (value selected per axis, not the pointer)
+    const bool f = t < nv && side[j] != 0;
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[(size_t)k * gridDim.x + blockIdx.x] = (wc[0] + wc[1]) + (wc[2] + wc[3]);
+}
+__global__ __launch_bounds__(1024) void k_presort_blockscan(const int* __restrict__ blk_cnt, int nblk, int* __restrict__ blk_off /* exclusive */) {
+    __shared__ int part[1024];
+    const int* in = blk_cnt + (size_t)blockIdx.x * nblk; int* out = blk_off + (size_t)blockIdx.x * nblk;
+    const int per = (nblk + 1023) / 1024, b0 = threadIdx.x * per;
+    int sum = 0;
+    for (int q = 0; q < per; q++) if (b0 + q < nblk) sum += in[b0 + q];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                  // Hillis-Steele over the 1024 thread sums
+        const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;                   // exclusive prefix of this thread's chunk
+    for (int q = 0; q < per; q++) if (b0 + q < nblk) { out[b0 + q] = run; run += in[b0 + q]; }
+}
+template <int DIM>
+__global__ __launch_bounds__(PRS_THREADS) void k_presort_scatter(const AxisLists<DIM> al, const unsigned char* __restrict__ side, const int* __restrict__ blk_off, int nv, int seg_shift,
+                                                                 AxisLists<DIM> out_lists) {
+    __shared__ int wc[PRS_THREADS / WAVE];
+    const int k = blockIdx.y, t = blockIdx.x * PRS_THREADS + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int j = 0;
+#pragma unroll
+    for (int q = 0; q < DIM; q++) { if (q == k) j = t < nv ? al.L[q][t] : 0; }
+    const bool f = t < nv && side[j] != 0;
+    const unsigned long long m = __ballot(f);
+    if (lane == 0) wc[w] = __popcll(m);
+    __syncthreads();
+    int before = __popcll(m & ((1ull << lane) - 1ull));
+    for (int ww = 0; ww < w; ww++) before += wc[ww];
     if (t >= nv) return;
-    const int j = Lk[t];
-    const int S = (t >> seg_shift) << seg_shift;
+    const int* off = blk_off + (size_t)k * gridDim.x;
+    const int S = (t >> seg_shift) << seg_shift;          // segment start: a multiple of 4096, i.e. of the block size
+    const int r_before = off[blockIdx.x] + before - off[S / PRS_THREADS];
     const int cnt = min(1 << seg_shift, nv - S), nleft = min(1 << (seg_shift - 1), cnt);
-    const int r_before = R[t] - R[S];
-    Lk_out[side[j] ? S + nleft + r_before : S + (t - S - r_before)] = j;
+    const int pos = f ? S + nleft + r_before : S + (t - S - r_before);
+#pragma unroll
+    for (int q = 0; q < DIM; q++) { if (q == k) ((int*)out_lists.L[q])[pos] = j; }
 }
 
 // The lower levels of the build in one kernel.  Once a node's slice is <= 2048 points the remaining levels only permute

@@ -11,7 +11,6 @@
 #include "icp_device.hpp"
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
-#include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 #include <cstdio>
@@ -74,7 +73,7 @@ struct icp_ctx {
     unsigned timing_phase = 0;           // rotates the sampled iterations from run to run
     void* pinned = nullptr; size_t pinned_cap = 0;   // page-locked host staging: pose upload, stats + pose download (truly asynchronous copies)
     bool block_levels = true;            // BVH build: levels with slices <= 2048 points in one LDS kernel (ICP_HIP_BLOCK_LEVELS=0: global sorts)
-    bool spin_reduce = false;            // k_reduce_solve: block 0 polls the self-validating totals (ICP_HIP_SPIN_REDUCE=1) instead of the ticket hand-over
+    bool spin_reduce = true;             // k_reduce_solve: block 0 polls the self-validating totals (ICP_HIP_SPIN_REDUCE=0: ticket hand-over, last arriver solves)
     bool presort = true;                 // BVH build: upper levels from presorted axes (ICP_HIP_PRESORT=0: one global sort per level)
     bool trace = false;                  // ICP_HIP_TRACE=1: per-iteration stage times on stderr
     bool fuse_post = true;               // BVH matcher runs weight / reject / accumulate as its epilogue (ICP_HIP_FUSE_POST=0 disables)
@@ -319,15 +318,14 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
             if (n_upper > 0) {
                 for (int k = 0; k < 2 * DIM; k++) if ((rc = ensure(c, b.axl[k], (size_t)cap * 4))) return rc;
                 if ((rc = ensure(c, b.side, (size_t)(b.n_ids > 0 ? b.n_ids : 1)))) return rc;
-                if ((rc = ensure(c, b.scanr, (size_t)cap * 4))) return rc;
                 if ((rc = ensure(c, b.axis_of_node, (size_t)1 << n_upper))) return rc;
                 unsigned int* k32 = b.keys.as<unsigned int>(); unsigned int* k32b = b.keys2.as<unsigned int>();
-                size_t tb = 0, tb2 = 0;
+                size_t tb = 0;
                 HIPCK(c, rocprim::radix_sort_pairs(nullptr, tb, k32, k32b, perm, perm2, (size_t)nv, 0, 32, c->stream));
-                SideOfEntry probe{b.side.as<unsigned char>(), b.axl[0].as<int>()};
-                auto in0 = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), probe);
-                HIPCK(c, rocprim::exclusive_scan(nullptr, tb2, in0, b.scanr.as<int>(), 0, (size_t)nv, rocprim::plus<int>(), c->stream));
-                if ((rc = ensure(c, b.temp, tb > tb2 ? (tb > temp_bytes ? tb : temp_bytes) : (tb2 > temp_bytes ? tb2 : temp_bytes)))) return rc;
+                if ((rc = ensure(c, b.temp, tb > temp_bytes ? tb : temp_bytes))) return rc;
+                const int nblk = (nv + PRS_THREADS - 1) / PRS_THREADS;
+                if ((rc = ensure(c, b.scanr, (size_t)2 * DIM * nblk * 4))) return rc;
+                int* blk_cnt = b.scanr.as<int>(); int* blk_off = blk_cnt + (size_t)DIM * nblk;
                 int* cur[DIM]; int* alt[DIM];
                 for (int k = 0; k < DIM; k++) {           // one stable sort per axis (ids arrive in increasing order: ties keep index order)
                     cur[k] = b.axl[k].as<int>(); alt[k] = b.axl[DIM + k].as<int>();
@@ -336,17 +334,14 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
                 }
                 for (int d = 0; d < n_upper; d++) {
                     int sh = 0; { long long seg = (long long)BVH_LEAF * b.Lp >> d; while ((1LL << sh) < seg) sh++; }
-                    AxisLists<DIM> al; for (int k = 0; k < DIM; k++) al.L[k] = cur[k];
+                    AxisLists<DIM> al, ao; for (int k = 0; k < DIM; k++) { al.L[k] = cur[k]; ao.L[k] = alt[k]; }
                     const int n_nodes = 1 << d;
                     hipLaunchKernelGGL(k_presort_axis<DIM>, dim3((n_nodes + 255) / 256), dim3(256), 0, c->stream, cp, al, nv, sh, n_nodes, b.axis_of_node.as<unsigned char>());
                     hipLaunchKernelGGL(k_presort_side<DIM>, dim3(gb), dim3(256), 0, c->stream, al, nv, sh, b.axis_of_node.as<unsigned char>(), b.side.as<unsigned char>());
-                    for (int k = 0; k < DIM; k++) {
-                        SideOfEntry fn{b.side.as<unsigned char>(), cur[k]};
-                        auto in = rocprim::make_transform_iterator(rocprim::counting_iterator<int>(0), fn);
-                        HIPCK(c, rocprim::exclusive_scan(b.temp.p, tb2, in, b.scanr.as<int>(), 0, (size_t)nv, rocprim::plus<int>(), c->stream));
-                        hipLaunchKernelGGL(k_presort_scatter, dim3(gb), dim3(256), 0, c->stream, cur[k], b.side.as<unsigned char>(), b.scanr.as<int>(), nv, sh, alt[k]);
-                        int* t = cur[k]; cur[k] = alt[k]; alt[k] = t;
-                    }
+                    hipLaunchKernelGGL(k_presort_count<DIM>, dim3(nblk, DIM), dim3(PRS_THREADS), 0, c->stream, al, b.side.as<unsigned char>(), nv, blk_cnt);
+                    hipLaunchKernelGGL(k_presort_blockscan, dim3(DIM), dim3(1024), 0, c->stream, blk_cnt, nblk, blk_off);
+                    hipLaunchKernelGGL(k_presort_scatter<DIM>, dim3(nblk, DIM), dim3(PRS_THREADS), 0, c->stream, al, b.side.as<unsigned char>(), blk_off, nv, sh, ao);
+                    for (int k = 0; k < DIM; k++) { int* t = cur[k]; cur[k] = alt[k]; alt[k] = t; }
                 }
                 HIPCK(c, hipMemcpyAsync(perm, cur[0], (size_t)nv * 4, hipMemcpyDeviceToDevice, c->stream));      // any list: the block kernel sorts inside its slices
                 HIPCK(c, hipGetLastError());

@@ -49,6 +49,26 @@ def test_lbvh_ties_duplicates_nonfinite(gpu_ctx_factory, orc):
     assert mo["idx"][0] == 30 and mo["idx"][5] == 50 and mo["idx"][6] == 999
 
 
+@pytest.mark.parametrize("m", [2049, 9000, 40000])
+def test_lbvh_heavy_ties_on_a_coarse_grid(gpu_ctx_factory, orc, m):
+    """Targets on a coarse lattice (every coordinate value shared by hundreds of points, many exact duplicates): the presorted-axes
+    build's stable partitions and the widest-axis choice meet ties at every level.  3-D and 6-D, bit-exact vs the oracle's scan."""
+    rng = np.random.default_rng(m)
+    t = (rng.integers(-12, 13, (m, 3)) * 0.125).astype(f32)
+    q = rng.uniform(-1.7, 1.7, (1500, 3)).astype(f32); q[:200] = t[rng.integers(0, m, 200)]       # some queries exactly on targets
+    c = ctx_with(gpu_ctx_factory, t, q, 4.0, LBVH)
+    mg, dg = c.match(np.eye(4))
+    mo, do = orc.knn3(q, t, 4.0)
+    assert np.array_equal(mg["idx"], mo["idx"]) and np.array_equal(bits(dg), bits(do))
+    tc = rng.integers(0, 4, (m, 4)).astype(np.uint8) * 60; qc = rng.integers(0, 4, (len(q), 4)).astype(np.uint8) * 60
+    c6 = gpu_ctx_factory()
+    c6.params.max_distance = 4.0; c6.params.knn_backend = LBVH; c6.params.color_icp = 1; c6.push_params()
+    c6.set_target(t, None, tc); c6.set_source(q, None, qc)
+    m6, d6 = c6.match(np.eye(4))
+    o6, od6 = orc.knn6(q, qc, t, tc, 4.0)
+    assert np.array_equal(m6["idx"], o6["idx"]) and np.array_equal(bits(d6), bits(od6))
+
+
 def test_lbvh_degenerate_targets(gpu_ctx_factory, orc):
     q = np.random.default_rng(1).uniform(-1, 1, (100, 3)).astype(f32)
     for t in (np.full((50, 3), np.nan, f32),                                   # nothing finite: empty tree
