@@ -278,8 +278,9 @@ def main():
     ap.add_argument("--n-tilt", type=int, default=344)
     ap.add_argument("--n-beam", type=int, default=1077)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stage-timing", type=int, default=5, help="bracket every Nth ICP iteration of the timed region with HIP events (offset rotates "
-                    "from step to step); 1 = every iteration, as the reference's TimeMeasure does (costs ~10 %% of an iteration)")
+    ap.add_argument("--stage-timing", type=int, default=10, help="bracket every Nth ICP iteration of the timed region with HIP events (offset rotates "
+                    "from step to step: after N steps every iteration index has been timed once); 1 = every iteration, as the reference's "
+                    "TimeMeasure does (costs ~10 %% of an iteration); an event bracket costs ~3 us of stream time")
     ap.add_argument("--no-incremental", action="store_true", help="always walk the BVH (disable the exact verify-and-skip of converged queries)")
     ap.add_argument("--no-cpu-baseline-detail", action="store_true", help="skip the SURVEY 8d CPU variants (i)-(iii) (a few seconds)")
     ap.add_argument("--resident-pairs", type=int, default=1, help="default mode: this many independent resident pairs per GPU, aligned concurrently "
