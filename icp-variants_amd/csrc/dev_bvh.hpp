@@ -500,9 +500,13 @@ __device__ __forceinline__ f2 pair_lb(const BvhNodeT<DIM>* __restrict__ nd, cons
 }
 
 // Evaluate the 8 points of a leaf against the lane's query; exact lexicographic (d2, lowest index) update.
-// best2 follows the smallest distance among all evaluated points OTHER than the current winner (see k_knn_bvh).
+// best2 follows the smallest distance among all evaluated points OTHER than the current winner (see k_knn_bvh); out2 the smallest
+// distance among the evaluated points of every leaf other than the WINNER'S LEAF (second verification tier, knn_leaf_bound): a leaf
+// that does not take the win contributes its minimum, a leaf that takes it sends the dethroned winner's distance -- the minimum of
+// the leaf the winner leaves -- there.  (A leaf visited while it already holds the winner contributes nothing.)
 template <int DIM>
-__device__ __forceinline__ void leaf_eval(const BvhLeafT<DIM>* __restrict__ lf, int leaf, const f2* p2, float& best, int& bi, int& bpos, float& best2) {
+__device__ __forceinline__ void leaf_eval(const BvhLeafT<DIM>* __restrict__ lf, int leaf, const f2* p2, float& best, int& bi, int& bpos, float& best2, float& out2) {
+    const int prev_leaf = bpos >> 3; const float prev_best = best;
     float dd[BVH_LEAF];
     float m = FLT_MAX;
 #pragma unroll
@@ -528,6 +532,7 @@ __device__ __forceinline__ void leaf_eval(const BvhLeafT<DIM>* __restrict__ lf, 
             best = take ? dd[t] : best; bi = take ? j : bi; bpos = take ? leaf * BVH_LEAF + t : bpos;
         }
     } else best2 = fminf(best2, m);      // nobody here can win: all 8 are "others"
+    if (leaf != prev_leaf) out2 = fminf(out2, (bpos >> 3) == leaf ? prev_best : m);
 }
 
 // Temporal seeding: ICP moves the queries a little per iteration, so the previous iteration's neighbour j0 is a
@@ -699,7 +704,7 @@ __device__ int g_dbg_nodes_dummy;
 #endif
 template <int DIM, class MaskT>
 __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<DIM>& qp, QuadStateT<MaskT>& st,
-                                         float& best, int& bi, int& bpos, float& best2, float& minlb, int& dbg_nodes, int& dbg_leaves) {
+                                         float& best, int& bi, int& bpos, float& best2, float& out2, float& minlb, int& dbg_nodes, int& dbg_leaves) {
     const int Lq = bv.Lq;
     // A box is skipped when its lower bound exceeds thr = best * (1 + 2e-5) (clamped so that the +inf bound of an empty box is
     // always skipped): that implies bound > best with margin, one multiply per change of `best` instead of one per box test.
@@ -729,7 +734,7 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<
         }
         if (st.alive) {
             ICP_COUNT_STEP(dbg_leaves);
-            leaf_eval<DIM>(bv.leaves + st.idx, st.idx, qp.p2, best, bi, bpos, best2);
+            leaf_eval<DIM>(bv.leaves + st.idx, st.idx, qp.p2, best, bi, bpos, best2, out2);
             thr = fminf(best * 1.00002f, FLT_MAX);
             st.alive = false;
             quad_pop_bits(st);
@@ -793,8 +798,9 @@ __device__ __forceinline__ bool knn_try_verify(const KnnParams& kp, const BvhVie
 }
 
 template <int DIM>
-__device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, const float* p, float best, int bpos, float lb_others) {
+__device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, const float* p, float best, int bpos, float lb_others, float lb_outleaf) {
     if (kp.qstate) { float4 s; s.x = p[0]; s.y = p[1]; s.z = p[2]; s.w = lb_others; kp.qstate[k] = s; }
+    if (kp.qstate2) kp.qstate2[k] = lb_outleaf;
     if (kp.nn_raw) kp.nn_raw[k] = bpos;
     if (kp.d2_out) kp.d2_out[k] = best;
 }
@@ -827,7 +833,7 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // bpos: that query and its seed, identical in all lanes of the group.  Returns (per lane, uniform in the group) whether the search
 // completed; false (outputs untouched) when the group's frontier would overflow -> that query falls back to the per-lane walk.
 template <int DIM, int NT>
-__device__ __forceinline__ bool coop_search(const BvhViewT<DIM>& bv, const float* q, bool gact, int lgS, float& best, int& bi, int& bpos, float& lb_others,
+__device__ __forceinline__ bool coop_search(const BvhViewT<DIM>& bv, const float* q, bool gact, int lgS, float& best, int& bi, int& bpos, float& lb_others, float& lb_outleaf,
                                             uint2* __restrict__ lbq, int tid) {
     const int lane = tid & 63, wbase = tid & ~63;          // this wave's slots: lbq[row * NT + wbase + col]
     const int S = 1 << lgS, gl = lane & (S - 1), g = lane >> lgS;
@@ -871,13 +877,13 @@ __device__ __forceinline__ bool coop_search(const BvhViewT<DIM>& bv, const float
         if (!__any(ok && n > 0)) break;
     }
     // leaves: one per lane and round; every lane starts from its group's seed
-    float b = best, b2 = FLT_MAX; int i = bi, ps = bpos;
+    float b = best, b2 = FLT_MAX, o2 = FLT_MAX; int i = bi, ps = bpos;
     for (int base = 0; __any(ok && base < n); base += S) {
         const int e = base + gl;
         if (ok && e < n) {
             const int E = e0 + e;
             const int leaf = (int)slot[2 * ((E >> 6) * NT + wbase + (E & 63)) + cur];
-            leaf_eval<DIM>(bv.leaves + leaf, leaf, qp.p2, b, i, ps, b2);
+            leaf_eval<DIM>(bv.leaves + leaf, leaf, qp.p2, b, i, ps, b2, o2);
         }
     }
     // minima over the group (xor-shuffles below S stay inside the aligned group)
@@ -892,20 +898,26 @@ __device__ __forceinline__ bool coop_search(const BvhViewT<DIM>& bv, const float
     const int wl = __ffsll((long long)mm) - 1;
     const int wps = __shfl(ps, wl < 0 ? lane : wl, WAVE);
     float others = mine ? b2 : fminf(b, b2);              // a lane whose local winner lost: that point is an "other" too
+    // ... and it lies outside the winner's leaf unless it sits in that very leaf (a lane that kept the seed while another lane found
+    // the winner in the seed's leaf); every leaf is evaluated by one lane only, so a lane's o2 never holds points of the winner's leaf
+    float outl = fminf(o2, (!mine && (ps >> 3) != (wps >> 3)) ? b : FLT_MAX);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(others, o, WAVE), u = __shfl_xor(minlb, o, WAVE); if (o < S) { others = fminf(others, t); minlb = fminf(minlb, u); } }
-    if (ok) { best = wb; bi = wi; bpos = wps; lb_others = sqrtf(fminf(others, minlb)) * 0.999999f; }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(others, o, WAVE), u = __shfl_xor(minlb, o, WAVE), v = __shfl_xor(outl, o, WAVE);
+        if (o < S) { others = fminf(others, t); minlb = fminf(minlb, u); outl = fminf(outl, v); }
+    }
+    if (ok) { best = wb; bi = wi; bpos = wps; lb_others = sqrtf(fminf(others, minlb)) * 0.999999f; lb_outleaf = sqrtf(fminf(outl, minlb)) * 0.999999f; }
     return ok;
 }
 
 // The tree walk proper for query p, starting from the seed (best, bi, bpos); returns the lower bound on the distance to every
 // target other than the winner.  NT = threads of the block (layout of the LDS stacks).
 template <int DIM, int NT>
-__device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* p, float& best, int& bi, int& bpos, uint2* __restrict__ lbq, int tid, int* dbg_out = nullptr) {
+__device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* p, float& best, int& bi, int& bpos, float& lb_outleaf, uint2* __restrict__ lbq, int tid, int* dbg_out = nullptr) {
     int dbg_nodes = 0, dbg_leaves = 0;
     QueryPt<DIM> qp;
     make_query<DIM>(bv, p, qp);
-    float best2 = FLT_MAX, minlb = FLT_MAX;
+    float best2 = FLT_MAX, out2 = FLT_MAX, minlb = FLT_MAX;
     unsigned int touched = 0u;
     if (ICP_SEED_DESCENT && bpos < 0 && bv.Lq > 0) {
         // No candidate yet (first iteration): one greedy root-to-leaf descent -- nearest child at every level, nothing parked --
@@ -919,21 +931,22 @@ __device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* 
             const int c = (l01.x == m) ? 0 : (l01.y == m) ? 1 : (l23.x == m) ? 2 : 3;
             idx = (idx << 2) | c;
         }
-        float unused = FLT_MAX;
-        leaf_eval<DIM>(bv.leaves + idx, idx, qp.p2, best, bi, bpos, unused);      // (the walk re-evaluates this leaf: the bound bookkeeping stays in one place)
+        float unused = FLT_MAX, unused2 = FLT_MAX;
+        leaf_eval<DIM>(bv.leaves + idx, idx, qp.p2, best, bi, bpos, unused, unused2);      // (the walk re-evaluates this leaf: the bound bookkeeping stays in one place)
     }
     if (ICP_PREFETCH_PATH && bpos >= 0) touched = quad_prefetch_path<DIM>(bv, bpos >> 3);
     if (bv.Lq <= 8) {                                     // uniform: up to 8 levels (524 288 targets) the pending bits fit 32 bits
         QuadStateT<unsigned int> st; st.L = 0; st.idx = 0; st.pending = 0u; st.alive = true;
-        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, minlb, dbg_nodes, dbg_leaves);
+        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, out2, minlb, dbg_nodes, dbg_leaves);
     } else {
         QuadStateT<unsigned long long> st; st.L = 0; st.idx = 0; st.pending = 0ull; st.alive = true;
-        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, minlb, dbg_nodes, dbg_leaves);
+        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, out2, minlb, dbg_nodes, dbg_leaves);
     }
 #if ICP_DEBUG_STEPS
     if (dbg_out) *dbg_out = dbg_nodes | (dbg_leaves << 16);
 #endif
     asm volatile("" ::"v"(touched));
+    lb_outleaf = sqrtf(fminf(out2, minlb)) * 0.999999f;
     return sqrtf(fminf(best2, minlb)) * 0.999999f;
 }
 
@@ -943,11 +956,13 @@ __device__ __forceinline__ void knn_bvh_query(const KnnParams& kp, const BvhView
     float p[DIM];
     knn_load_query<DIM>(kp, k, p);
     best = FLT_MAX; bi = -1; bpos = -1;
-    float lb_others = 0.f;               // lower bound on the (real) distance from p to every target except bi
+    float lb_others = 0.f, lb_outleaf = 0.f;      // lower bounds on the (real) distance from p to every target except bi / outside bi's leaf
     if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
-        if (!knn_try_verify<DIM>(kp, bv, k, p, best, bi, bpos, lb_others)) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lbq, tid);
+        // (a query verified here re-anchors; its leaf bound shrinks by the same step: lb_others is already L - delta)
+        if (knn_try_verify<DIM>(kp, bv, k, p, best, bi, bpos, lb_others)) lb_outleaf = lb_others;
+        else lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lb_outleaf, lbq, tid);
     }
-    knn_store_state<DIM>(kp, k, p, best, bpos, lb_others);
+    knn_store_state<DIM>(kp, k, p, best, bpos, lb_others, lb_outleaf);
 }
 
 // Which query does this lane serve?  Position t of the (Morton-sorted) query order, in XCD-contiguous slices.

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
     float rn0 = 0.f, rn1 = 0.f, rn2 = 0.f;
     float best = FLT_MAX, lb_others = 0.f; int bi = -1, bpos = -1, q0 = -1;
     float4 ra, rb; ra.x = 0.f; ra.y = 0.f; ra.z = 0.f; ra.w = 0.f; rb = ra;
-    bool need_walk = false, verified = false;
+    bool need_walk = false, verified = false, leaf_only = false;
+    float lb_outleaf = 0.f;                               // bound on every target outside the winner's leaf (second verification tier)
     if (k >= 0) {
         // ---- front end.  Everything that depends only on the query index is requested in ONE batch (point, normal, previous
         // neighbour, search state), then the neighbour's record: two memory round trips before the verify test instead of
@@ -61,7 +62,8 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
         const bool seeded = kp.use_prev != 0, inc = kp.incremental && seeded;
         q0 = seeded ? kp.nn_raw[k] : -1;
         float4 st; st.x = 0.f; st.y = 0.f; st.z = 0.f; st.w = 0.f;
-        if (inc) st = kp.qstate[k];
+        float st2 = 0.f;
+        if (inc) { st = kp.qstate[k]; if (kp.qstate2) st2 = kp.qstate2[k]; }
         xform_point(kp.ps->pose, r0, r1, r2, p[0], p[1], p[2]);
         if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
             need_walk = true;
@@ -83,9 +85,24 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
                     const float delta = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.000001f + 1e-30f;
                     const float lbn = (st.w - delta) * 0.999999f;
                     if (sqrtf(best) * 1.000001f < lbn) { lb_others = lbn; need_walk = false; verified = true; }
+                    else {
+                        // second tier: every target OUTSIDE the neighbour's leaf is still provably farther than the neighbour itself ->
+                        // the nearest neighbour is one of that leaf's 8 points: one leaf evaluation instead of a walk
+                        const float lb2 = (st2 - delta) * 0.999999f;
+                        if (sqrtf(best) * 1.000001f < lb2) { leaf_only = true; lb_outleaf = lb2; }
+                    }
                 }
             }
         }
+    }
+    if (leaf_only) {
+        f2 p2[DIM];
+#pragma unroll
+        for (int q = 0; q < DIM; q++) { p2[q].x = p[q]; p2[q].y = p[q]; }
+        float b2 = FLT_MAX, o2 = FLT_MAX;
+        leaf_eval<DIM>(bv.leaves + (q0 >> 3), q0 >> 3, p2, best, bi, bpos, b2, o2);      // exact argmin over the leaf, seeded with the old neighbour
+        lb_others = fminf(sqrtf(b2) * 0.999999f, lb_outleaf);                           // re-anchored here: second best of the leaf, or anything outside it
+        need_walk = false;
     }
     // ---- the walks.  A wave left with at most ICP_COOP_MAX seeded queries to search does them cooperatively, all at once, one per
     // group of lanes (coop_search); otherwise every lane walks on its own.
@@ -104,26 +121,26 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
             float q[DIM];
 #pragma unroll
             for (int a = 0; a < DIM; a++) q[a] = __shfl(p[a], src, WAVE);
-            float b = __shfl(best, src, WAVE), lbo = 0.f; int ci = __shfl(bi, src, WAVE), cps = __shfl(bpos, src, WAVE);
-            const bool done = coop_search<DIM, BVH_THREADS>(bv, q, gact, lgS, b, ci, cps, lbo, bvh_lbq, tid);
+            float b = __shfl(best, src, WAVE), lbo = 0.f, lbo2 = 0.f; int ci = __shfl(bi, src, WAVE), cps = __shfl(bpos, src, WAVE);
+            const bool done = coop_search<DIM, BVH_THREADS>(bv, q, gact, lgS, b, ci, cps, lbo, lbo2, bvh_lbq, tid);
             // the result travels back to the source lane: it reads it from the first lane of the group that searched for it
             const int gsrc = __popcll(wm & ((1ull << lane) - 1ull));                 // my rank among the walkers = the group that served me
             const int from = min(gsrc, 15) << lgS;
-            const float rb = __shfl(b, from, WAVE), rl = __shfl(lbo, from, WAVE); const int ri = __shfl(ci, from, WAVE), rp = __shfl(cps, from, WAVE);
+            const float rb = __shfl(b, from, WAVE), rl = __shfl(lbo, from, WAVE), rl2 = __shfl(lbo2, from, WAVE); const int ri = __shfl(ci, from, WAVE), rp = __shfl(cps, from, WAVE);
             const bool rdone = __shfl((int)done, from, WAVE) != 0;
-            if (need_walk && rdone) { best = rb; bi = ri; bpos = rp; lb_others = rl; need_walk = false; }
+            if (need_walk && rdone) { best = rb; bi = ri; bpos = rp; lb_others = rl; lb_outleaf = rl2; need_walk = false; }
         }
     }
 #if ICP_DEBUG_STEPS
-    if (k >= 0 && kp.dbg_steps) kp.dbg_steps[k] = need_walk ? -1 : 0;      // -1: a cooperative search took it (overwritten by a per-lane walk)
+    if (k >= 0 && kp.dbg_steps) kp.dbg_steps[k] = need_walk ? -1 : leaf_only ? -2 : 0;      // -1: walk (overwritten with its length); -2: second tier, one leaf
 #endif
-    if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, bvh_lbq, tid, (ICP_DEBUG_STEPS && kp.dbg_steps) ? kp.dbg_steps + k : nullptr);
+    if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lb_outleaf, bvh_lbq, tid, (ICP_DEBUG_STEPS && kp.dbg_steps) ? kp.dbg_steps + k : nullptr);
     if (k >= 0) {
         // A verified query keeps its stored anchor (position of the last full search) and bound: the triangle test stays valid
         // against the OLD anchor -- and is tighter than re-anchoring, (L - d1) - d2 <= L - |d1 + d2| -- and its neighbour is
         // unchanged, so nothing of its search state needs rewriting.  Once ICP has converged that is > 99.9 % of the queries:
         // the 28 B per query of state stores (and the Match record, when nobody reads it) disappear from those launches.
-        if (!verified) knn_store_state<DIM>(kp, k, p, best, bpos, lb_others);
+        if (!verified) knn_store_state<DIM>(kp, k, p, best, bpos, lb_others, lb_outleaf);
         else if (kp.d2_out) kp.d2_out[k] = best;
         icp_match_t m;
         if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }

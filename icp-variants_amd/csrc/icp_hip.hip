@@ -74,6 +74,7 @@ struct icp_ctx {
     void* pinned = nullptr; size_t pinned_cap = 0;   // page-locked host staging: pose upload, stats + pose download (truly asynchronous copies)
     bool block_levels = true;            // BVH build: levels with slices <= 2048 points in one LDS kernel (ICP_HIP_BLOCK_LEVELS=0: global sorts)
     bool spin_reduce = true;             // k_reduce_solve: block 0 polls the self-validating totals (ICP_HIP_SPIN_REDUCE=0: ticket hand-over, last arriver solves)
+    bool tier2 = true;                   // incremental k-NN: second verification tier (one leaf instead of a walk; ICP_HIP_TIER2=0 disables)
     bool presort = true;                 // BVH build: upper levels from presorted axes (ICP_HIP_PRESORT=0: one global sort per level)
     bool trace = false;                  // ICP_HIP_TRACE=1: per-iteration stage times on stderr
     bool fuse_post = true;               // BVH matcher runs weight / reject / accumulate as its epilogue (ICP_HIP_FUSE_POST=0 disables)
@@ -87,7 +88,7 @@ struct icp_ctx {
     DevBuf okeys, okeys2, ovals, otemp;  // scratch of the Morton sort of the queries
     std::map<int, Level> levels;         // multires selections by decimation factor
     DevBuf sel_lists, sel_counts, sel_blocks;            // RANDOM_SAMPLING: per-iteration index lists, their sizes, scan scratch
-    DevBuf qstate;                                       // incremental k-NN: per-query position + bound on the other targets
+    DevBuf qstate, qstate2;                              // incremental k-NN: per-query anchor + bound on the other targets; bound on the targets outside the neighbour's leaf
     DevBuf dbg_steps;                    // development builds only (ICP_DEBUG_STEPS)
     DevBuf ps, matches, d2, best64, nn_raw, partials, totals, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
     Cloud conv_src, conv_ref; int conv_n = 0;
@@ -474,7 +475,7 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr) {
     kp.tx = c->tgt.x.as<float>(); kp.ty = c->tgt.y.as<float>(); kp.tz = c->tgt.z.as<float>();
     kp.tcr = c->tgt.cr.as<float>(); kp.tcg = c->tgt.cg.as<float>(); kp.tcb = c->tgt.cb.as<float>();
     kp.mpad = c->tgt.npad; kp.ps = c->ps.as<PoseState>(); kp.pretransformed = q.pretransformed; kp.max_dist = p.max_distance;
-    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0; kp.qstate = nullptr; kp.incremental = 0; kp.dbg_steps = nullptr;
+    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0; kp.qstate = nullptr; kp.qstate2 = nullptr; kp.incremental = 0; kp.dbg_steps = nullptr;
     if (p.knn_backend == ICP_KNN_LBVH) {
         kp.nseg = 1;
         if ((rc = ensure(c, c->nn_raw, (size_t)q.n * 4))) return rc;
@@ -485,7 +486,8 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr) {
 #endif
         if (p.knn_incremental && !q.pretransformed) {
             if ((rc = ensure(c, c->qstate, (size_t)q.n * 16))) return rc;
-            kp.qstate = c->qstate.as<float4>(); kp.incremental = 1;
+            if ((rc = ensure(c, c->qstate2, (size_t)q.n * 4))) return rc;
+            kp.qstate = c->qstate.as<float4>(); kp.qstate2 = c->tier2 ? c->qstate2.as<float>() : nullptr; kp.incremental = 1;
         }
         const Cloud* fuse = (fused_blocks != nullptr && p.metric != ICP_METRIC_SYMMETRIC && !q.pretransformed) ? q.cl : nullptr;
         if (q.use_colors) return launch_bvh_query<6>(c, c->bvh6, target_coords6(c), kp, q.order, q.n, fuse, fused_blocks);
@@ -668,6 +670,7 @@ int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) { delete c; return ICP_ERR_HIP; }
     { const char* e = getenv("ICP_HIP_FUSE_POST"); if (e && e[0] == '0') c->fuse_post = false; }
     { const char* e = getenv("ICP_HIP_SPIN_REDUCE"); if (e) c->spin_reduce = e[0] == '1'; }
+    { const char* e = getenv("ICP_HIP_TIER2"); if (e && e[0] == '0') c->tier2 = false; }
     { const char* e = getenv("ICP_HIP_PRESORT"); if (e && e[0] == '0') c->presort = false; }
     { const char* e = getenv("ICP_HIP_BLOCK_LEVELS"); if (e && e[0] == '0') c->block_levels = false; }
     { const char* e = getenv("ICP_HIP_TRACE"); if (e && e[0] == '1') c->trace = true; }
@@ -697,7 +700,7 @@ int icp_ctx_destroy(icp_ctx* c) {
     for (Bvh* b : {&c->bvh6, &c->nrm_bvh}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
     release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) release(kv.second);
-    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->dbg_steps); release(c->sums);
+    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->qstate2); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->dbg_steps); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
     for (DevBuf* d : {&c->src_flag, &c->src_box, &c->tgt_flag, &c->tgt_finite, &c->nrm_finite, &c->sel_temp, &c->d_count}) release(*d);
     if (c->pin_up) (void)hipHostFree(c->pin_up);
