@@ -47,24 +47,10 @@ typedef BvhLeafT<3> BvhLeaf;
 // that chain, not by bytes or flops.
 template <int DIM> struct BvhQuadT { float lo[DIM][4]; float hi[DIM][4]; float pad[DIM == 3 ? 8 : 16]; };   // padded to one / two 128-byte lines
 
-// Quantised form of the same 4-wide node (ICP_QUANT_NODES=1): the child boxes on a uniform 14-bit grid over the bounding box of the
-// tree, 2 bytes per bound -- 48 B instead of 96 B per 3-D node, three 16-byte loads per lane and step instead of six.  The walk is
-// bound by the number of divergent 16-byte loads the texture path has to serve (every lane reads its own node) and by the latency of
-// that queue, not by arithmetic.  Conservative by construction: lower bounds are rounded down and upper bounds up (with a margin
-// that covers the fp32 rounding of the grid mapping), the query is widened to the grid cell interval that contains it, and the box
-// distance is evaluated in integer arithmetic (saturating packed u16 subtractions, exact squares, exact sums) -- so the bound never
-// exceeds the true box distance and the search stays exact; a box is only ever visited a little earlier than with fp32 boxes.
-// Layout: lo[k][0] = children (0, 1) as two u16 in one dword, lo[k][1] = children (2, 3); likewise hi.  An EMPTY child has
-// lo[0] = 0xFFFF, hi[0] = 0 and neutral other axes: its "distance" is >= QEMPTY_ACC, which no real box can reach.
-#ifndef ICP_QUANT_NODES
-#define ICP_QUANT_NODES 0
-#endif
-constexpr int QGRID_MAX = (1 << 14) - 1;                   // grid coordinates 0 .. 16383: 6 x 16383^2 < 2^31 <= QEMPTY_ACC <= 65535^2 < 2^32
-constexpr unsigned int QEMPTY_ACC = 0x80000000u;
-struct BvhGrid { float origin[6]; float inv_delta; float delta2; float pad[8]; };      // grid coordinate g = (x - origin) * inv_delta; delta2 = cell size squared
-template <int DIM> struct BvhQuadQT { unsigned int lo[DIM][2]; unsigned int hi[DIM][2]; unsigned int pad[DIM == 3 ? 4 : 8]; };   // 64 B / 128 B
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-
+// (Round 2 measured a QUANTISED form of these nodes -- child boxes on a uniform 14-bit grid, 48 B per node, integer box test with
+// saturating packed-u16 arithmetic, conservative by construction -- and dropped it: half the node loads, 60 % more VALU per node,
+// iterations 1-9 unchanged, the unseeded iteration twice as slow.  The walk is not bound by L1 bytes.  See DESIGN.md section 4; the
+// code is in the history: commit "quantised 4-wide nodes and XCD chunking as build variants".)
 // Everything the loop needs about a matched target point in ONE 32-byte record, stored in kd (leaf) order -- position
 // pos = 8 * leaf + slot.  Neighbouring (Morton-sorted) queries match neighbouring positions, so the gather of the
 // correspondence (point, normal, colour) is one sector per query instead of seven scattered planes.
@@ -77,8 +63,6 @@ template <int DIM> struct BvhViewT {
     const BvhNodeT<DIM>* nodes;   // [Lp - 1] internal nodes in heap order (node k: children 2k+1, 2k+2; leaves start at Lp-1)
     const TgtRec* recs;           // [8 * max(n_leaves,1)] point + normal + colour + original index by position
     const BvhQuadT<DIM>* qnodes;  // [(4^Lq - 1) / 3] 4-wide nodes, level l at offset (4^l - 1) / 3; the children of level Lq - 1 are the leaves
-    const BvhQuadQT<DIM>* qq;     // the same nodes quantised (ICP_QUANT_NODES)
-    const BvhGrid* grid;          // ... and their grid
     int Lq;                       // 4-wide levels = ceil(log2(Lp) / 2)  (an odd binary depth gets a virtual root with one empty half)
     int n_valid;                  // finite target points in the tree
     int Lp;                       // leaves rounded up to a power of two
@@ -443,46 +427,6 @@ __global__ void k_bvh_quad_nodes(const BvhNodeT<DIM>* __restrict__ nodes, int pa
     for (int k = 0; k < DIM; k++) { qnodes[q].lo[k][c] = lo[k]; qnodes[q].hi[k][c] = hi[k]; }
 }
 
-// Grid of the quantised nodes: uniform cell size over the root box (two cells of slack on every side).
-template <int DIM>
-__global__ void k_bvh_grid(const BvhNodeT<DIM>* __restrict__ nodes, BvhGrid* __restrict__ grid) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float ext = 0.f, lo[DIM];
-#pragma unroll
-    for (int k = 0; k < DIM; k++) {
-        lo[k] = fminf(nodes[0].lo[k][0], nodes[0].lo[k][1]);
-        const float hi = fmaxf(nodes[0].hi[k][0], nodes[0].hi[k][1]);
-        ext = fmaxf(ext, hi - lo[k]);
-    }
-    float delta = ext / (float)(QGRID_MAX - 4);
-    if (!(delta > 0.f) || !isfinite(delta)) delta = 1.f;
-    const float inv = 1.f / delta;
-    for (int k = 0; k < 6; k++) grid->origin[k] = k < DIM ? lo[k] - 2.f * delta : 0.f;
-    grid->inv_delta = inv;
-    const double d = 1.0 / (double)inv;                   // the cell size the stored inverse stands for
-    grid->delta2 = (float)(d * d);
-}
-__device__ __forceinline__ float grid_coord(const BvhGrid* __restrict__ g, int k, float x) { return (x - g->origin[k]) * g->inv_delta; }
-template <int DIM>
-__global__ void k_bvh_quantize(const BvhQuadT<DIM>* __restrict__ qnodes, int n_nodes, const BvhGrid* __restrict__ grid, BvhQuadQT<DIM>* __restrict__ out) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_nodes * 4) return;
-    const int q = t >> 2, c = t & 3;
-    const bool empty = !(qnodes[q].lo[0][c] <= qnodes[q].hi[0][c]);
-#pragma unroll
-    for (int k = 0; k < DIM; k++) {
-        int l, h;
-        if (empty) { l = k == 0 ? 0xFFFF : 0; h = k == 0 ? 0 : 0xFFFF; }
-        else {
-            // 0.05 cells of margin: the fp32 error of grid_coord is below 0.01 cells at the far end of the grid
-            l = (int)floorf(grid_coord(grid, k, qnodes[q].lo[k][c]) - 0.05f); h = (int)ceilf(grid_coord(grid, k, qnodes[q].hi[k][c]) + 0.05f);
-            l = min(max(l, 0), QGRID_MAX); h = min(max(h, 0), QGRID_MAX);
-        }
-        ((unsigned short*)&out[q].lo[k][0])[c] = (unsigned short)l;
-        ((unsigned short*)&out[q].hi[k][0])[c] = (unsigned short)h;
-    }
-}
-
 // Lower bounds of the fp32 squared distance from the query to any point of the two child boxes, both at once (packed
 // f32), accumulated in the SAME order as the point distance: ((e0^2 + e1^2) + e2^2) [+ e3^2 + e4^2 + e5^2].
 template <int DIM>
@@ -594,56 +538,17 @@ __device__ __forceinline__ void quad_lb(const BvhQuadT<DIM>* __restrict__ nd, co
     }
 }
 
-// The query as the node tests need it: packed fp32 pairs for the leaves (and the fp32 nodes), the grid cell interval for the
-// quantised nodes (low half = floor, high half = ceil, margins as in k_bvh_quantize).
-template <int DIM> struct QueryPt {
-    f2 p2[DIM];
-#if ICP_QUANT_NODES
-    unsigned int pq[DIM]; float delta2;
-#endif
-};
+// The query as the node and leaf tests need it: packed fp32 pairs.
+template <int DIM> struct QueryPt { f2 p2[DIM]; };
 template <int DIM>
 __device__ __forceinline__ void make_query(const BvhViewT<DIM>& bv, const float* p, QueryPt<DIM>& q) {
 #pragma unroll
     for (int k = 0; k < DIM; k++) { q.p2[k].x = p[k]; q.p2[k].y = p[k]; }
-#if ICP_QUANT_NODES
-    const BvhGrid* __restrict__ g = bv.grid;
-    q.delta2 = g->delta2;
-#pragma unroll
-    for (int k = 0; k < DIM; k++) {
-        const float gq = fminf(fmaxf(grid_coord(g, k, p[k]), -1.f), (float)QGRID_MAX + 1.f);      // a query outside the grid clamps towards it: still conservative
-        const int l = min(max((int)floorf(gq - 0.05f), 0), QGRID_MAX), h = min(max((int)ceilf(gq + 0.05f), 0), QGRID_MAX);
-        q.pq[k] = (unsigned int)l | ((unsigned int)h << 16);
-    }
-#endif
 }
-#if ICP_QUANT_NODES
-__device__ __forceinline__ us2 as_us2(unsigned int v) { return __builtin_bit_cast(us2, v); }
-template <int DIM>
-__device__ __forceinline__ void quad_lb_q(const BvhQuadQT<DIM>* __restrict__ nd, const QueryPt<DIM>& q, f2& l01, f2& l23) {
-    unsigned int acc[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int k = 0; k < DIM; k++) {
-        const us2 pq = as_us2(q.pq[k]);
-        const us2 pl = {pq.x, pq.x}, ph = {pq.y, pq.y};
-        const uint2 lo = *(const uint2*)nd->lo[k], hi = *(const uint2*)nd->hi[k];
-        const us2 e01 = __builtin_elementwise_max(__builtin_elementwise_sub_sat(as_us2(lo.x), ph), __builtin_elementwise_sub_sat(pl, as_us2(hi.x)));
-        const us2 e23 = __builtin_elementwise_max(__builtin_elementwise_sub_sat(as_us2(lo.y), ph), __builtin_elementwise_sub_sat(pl, as_us2(hi.y)));
-        acc[0] += (unsigned int)e01.x * (unsigned int)e01.x; acc[1] += (unsigned int)e01.y * (unsigned int)e01.y;
-        acc[2] += (unsigned int)e23.x * (unsigned int)e23.x; acc[3] += (unsigned int)e23.y * (unsigned int)e23.y;
-    }
-    l01.x = acc[0] >= QEMPTY_ACC ? INFINITY : (float)acc[0] * q.delta2; l01.y = acc[1] >= QEMPTY_ACC ? INFINITY : (float)acc[1] * q.delta2;
-    l23.x = acc[2] >= QEMPTY_ACC ? INFINITY : (float)acc[2] * q.delta2; l23.y = acc[3] >= QEMPTY_ACC ? INFINITY : (float)acc[3] * q.delta2;
-}
-#endif
 // lower bounds of the four children of 4-wide node `node` (index over all levels)
 template <int DIM>
 __device__ __forceinline__ void quad_lb_at(const BvhViewT<DIM>& bv, unsigned int node, const QueryPt<DIM>& q, f2& l01, f2& l23) {
-#if ICP_QUANT_NODES
-    quad_lb_q<DIM>(bv.qq + node, q, l01, l23);
-#else
     quad_lb<DIM>(bv.qnodes + node, q.p2, l01, l23);
-#endif
 }
 
 // The walk is a chain of dependent loads, each a trip to L2 or HBM.  A seeded query already knows where it will most
@@ -660,15 +565,9 @@ __device__ __forceinline__ unsigned int quad_prefetch_path(const BvhViewT<DIM>& 
 #pragma unroll
     for (int u = 0; u < 8; u++) {                         // branch-free (levels above the root clamp to the root): the loads issue back to back
         const int L = max(bv.Lq - 1 - u, 0), sh = min(2 * (u + 1), 2 * bv.Lq);
-#if ICP_QUANT_NODES
-        const unsigned int* nd = (const unsigned int*)(bv.qq + ((0x5555555555555555ull & ((1ull << (2 * L)) - 1ull)) + (unsigned long long)(leaf >> sh)));
-        t[u] = nd[11];
-        if (DIM == 6) t[u] |= nd[23];
-#else
         const unsigned int* nd = (const unsigned int*)(bv.qnodes + ((0x5555555555555555ull & ((1ull << (2 * L)) - 1ull)) + (unsigned long long)(leaf >> sh)));
         t[u] = nd[31];
         if (DIM == 6) t[u] |= nd[63];
-#endif
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) sink |= t[u];
@@ -746,20 +645,11 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<
 // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (block b runs on the XCD group b % 8), each
 // with a private 4 MiB L2.  With Morton-sorted queries, giving every XCD group ONE contiguous slice of the sorted list
 // means its L2 only has to hold the part of the tree under that slice (plus the shared top levels) instead of all of it.
-#ifndef ICP_XCD_CHUNK
-#define ICP_XCD_CHUNK 0          // 0: one contiguous slice per XCD group; C > 0: slices of C consecutive blocks dealt round-robin (load balance vs locality)
-#endif
+// (Measured in round 2 and dropped: slices of 8 / 32 consecutive blocks dealt round-robin instead -- balance against locality --
+// 20.7 k / 21.1 k vs 21.1 k iterations/s.)
 __device__ __forceinline__ int xcd_contiguous_block(int b, int nb) {
-#if ICP_XCD_CHUNK > 0
-    constexpr int C = ICP_XCD_CHUNK;
-    const int full = (nb / (8 * C)) * (8 * C);           // the part that divides evenly; the rest keeps its place
-    if (b >= full) return b;
-    const int x = b & 7, j = b >> 3;
-    return (j / C) * (8 * C) + x * C + (j % C);
-#else
     const int q = nb >> 3, r = nb & 7, x = b & 7, j = b >> 3;        // XCD group x owns q (+1 if x < r) consecutive logical blocks
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-#endif
 }
 
 // Every lane walks the tree on its own for its own query.  Measured on MI355X (370k x 370k, DIM 3): 12.5 4-wide nodes and

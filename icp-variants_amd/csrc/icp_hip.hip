@@ -54,7 +54,7 @@ struct Level { DevBuf idx; DevBuf order; DevBuf sorted_idx; Cloud sorted; bool s
 struct Bvh {
     bool valid = false;
     int n_valid = 0, n_leaves = 0, Lp = 1;
-    DevBuf keys, keys2, vals, vals2, temp, leaves, recs, nodes, qnodes, qq, grid, lvl, wbox;
+    DevBuf keys, keys2, vals, vals2, temp, leaves, recs, nodes, qnodes, lvl, wbox;
     DevBuf axl[12], side, scanr, axis_of_node;      // presorted-axes build: DIM index lists (ping-pong), side flag per point id, scan result, widest axis per node
     int n_ids = 0;                                   // size of the id space the lists index (points of the cloud the tree is built over)
     const Cloud* attrs = nullptr;                     // cloud whose normals / colours go into the records (nullptr: none)
@@ -388,14 +388,6 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
         const long long nq = ((1ll << (2 * b.Lq)) - 1) / 3;
         if ((rc = ensure(c, b.qnodes, (size_t)(nq > 0 ? nq : 1) * sizeof(BvhQuadT<DIM>)))) return rc;
         if (nq > 0) hipLaunchKernelGGL(k_bvh_quad_nodes<DIM>, dim3((unsigned)((nq * 4 + 255) / 256)), dim3(256), 0, c->stream, b.nodes.as<BvhNodeT<DIM>>(), pad, b.Lq, b.qnodes.as<BvhQuadT<DIM>>());
-#if ICP_QUANT_NODES
-        if ((rc = ensure(c, b.qq, (size_t)(nq > 0 ? nq : 1) * sizeof(BvhQuadQT<DIM>)))) return rc;
-        if ((rc = ensure(c, b.grid, sizeof(BvhGrid)))) return rc;
-        if (nq > 0) {
-            hipLaunchKernelGGL(k_bvh_grid<DIM>, dim3(1), dim3(64), 0, c->stream, b.nodes.as<BvhNodeT<DIM>>(), b.grid.as<BvhGrid>());
-            hipLaunchKernelGGL(k_bvh_quantize<DIM>, dim3((unsigned)((nq * 4 + 255) / 256)), dim3(256), 0, c->stream, b.qnodes.as<BvhQuadT<DIM>>(), (int)nq, b.grid.as<BvhGrid>(), b.qq.as<BvhQuadQT<DIM>>());
-        }
-#endif
     }
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipEventRecord(e1, c->stream));
@@ -432,7 +424,7 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
     int rc;
     if (!b.valid && (rc = build_bvh<DIM>(c, b, cp))) return rc;
     BvhViewT<DIM> bv; bv.leaves = b.leaves.as<BvhLeafT<DIM>>(); bv.nodes = b.nodes.as<BvhNodeT<DIM>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
-    bv.qnodes = b.qnodes.as<BvhQuadT<DIM>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>(); bv.qq = b.qq.as<BvhQuadQT<DIM>>(); bv.grid = b.grid.as<BvhGrid>();
+    bv.qnodes = b.qnodes.as<BvhQuadT<DIM>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>();
     const int nb = (n + BVH_THREADS - 1) / BVH_THREADS;
     const size_t stack_bytes = (size_t)(b.Lq > 0 ? b.Lq : 1) * BVH_THREADS * 8;
     if (fuse) {
@@ -642,7 +634,7 @@ int ensure_events(icp_ctx* c, size_t count) {
 
 extern "C" {
 
-const char* icp_version(void) { return ICP_QUANT_NODES ? "icp_hip gfx950 r2 (quantised nodes)" : "icp_hip gfx950 r2"; }
+const char* icp_version(void) { return "icp_hip gfx950 r2"; }
 
 uint32_t icp_select_hash(uint32_t seed, uint32_t iteration, uint32_t index) { return select_hash(seed, iteration, index); }
 
@@ -696,7 +688,7 @@ int icp_ctx_destroy(icp_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     release(c->tgt); release(c->src); release(c->qry); release(c->conv_src); release(c->conv_ref);
     release(c->nrm_cloud);
-    for (Bvh* b : {&c->bvh, &c->bvh6, &c->nrm_bvh}) { release(b->qnodes); release(b->recs); release(b->qq); release(b->grid); for (DevBuf& d : b->axl) release(d); release(b->side); release(b->scanr); release(b->axis_of_node); }
+    for (Bvh* b : {&c->bvh, &c->bvh6, &c->nrm_bvh}) { release(b->qnodes); release(b->recs); for (DevBuf& d : b->axl) release(d); release(b->side); release(b->scanr); release(b->axis_of_node); }
     for (Bvh* b : {&c->bvh6, &c->nrm_bvh}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
     release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) release(kv.second);
@@ -1131,7 +1123,7 @@ int icp_estimate_normals(icp_ctx* c, const float* xyz, int32_t n, int32_t k, con
     CoordPtrs<3> cp; cp.c[0] = cl.x.as<float>(); cp.c[1] = cl.y.as<float>(); cp.c[2] = cl.z.as<float>();
     if ((rc = build_bvh<3>(c, b, cp))) return rc;
     BvhViewT<3> bv; bv.leaves = b.leaves.as<BvhLeafT<3>>(); bv.nodes = b.nodes.as<BvhNodeT<3>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
-    bv.qnodes = b.qnodes.as<BvhQuadT<3>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>(); bv.qq = b.qq.as<BvhQuadQT<3>>(); bv.grid = b.grid.as<BvhGrid>();
+    bv.qnodes = b.qnodes.as<BvhQuadT<3>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>();
     int depth = 0; while ((1 << depth) < b.Lp) depth++;
     if ((rc = ensure(c, c->staging, (size_t)n * 16))) return rc;
     float* d_n = c->staging.as<float>(); float* d_c = d_n + (size_t)n * 3;
