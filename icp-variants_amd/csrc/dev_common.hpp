@@ -16,7 +16,7 @@ struct PoseState {
     float nmat[9];
     float mean_s[3];       // unweighted means of the current valid correspondences (symmetric ICP)
     float mean_d[3];
-    float pad;
+    int fault;             // set by the device when a bounded wait ran out (k_reduce_solve's hand-over): the run reports ICP_ERR_HIP
 };
 
 struct SoA3 { const float* x; const float* y; const float* z; };

@@ -421,7 +421,7 @@ __device__ __forceinline__ void solve_tail(const SolveParams& sp, const double* 
 // counter, release/acquire fences at agent scope) gathers the NSUM totals and runs the small fp64 solve + pose composition.
 constexpr int SOLVE_THREADS = 256;
 constexpr unsigned long long TOTAL_SENTINEL = 0xFFF8D1CEC0DE5EEDull;      // a NaN payload no arithmetic produces: "total not written yet"
-constexpr int SPIN_LIMIT = 1 << 16;
+constexpr int SPIN_LIMIT = 1 << 22;                        // polls of ~1 us: seconds, not a hang
 constexpr int SOLVE_INFLIGHT = 12;                        // loads in flight per thread: 12 x 256 = 3072 partials in ONE memory round trip
 __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParams sp) {
     __shared__ double tot[NSUM];
@@ -450,8 +450,8 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
         // but the sentinel the slots hold between launches), so nothing has to be ordered against anything: block 0 -- always
         // resident, like the other 33 -- polls the 34 slots with sc1 loads, one lane per slot, takes the values, puts the sentinels
         // back and solves.  Against store -> drain -> ticket -> re-load that is two dependent trips to memory less per launch.  The
-        // wait is bounded: after SPIN_LIMIT polls (~ tens of ms) a slot is taken as it is -- a total that happens to BE the sentinel
-        // bit pattern (a NaN with that payload) cannot hang the launch.
+        // wait is bounded: after SPIN_LIMIT polls (seconds) the launch gives up, raises PoseState::fault and the run reports
+        // ICP_ERR_HIP instead of hanging or solving with a slot that was never written.
         if (threadIdx.x == 0) {
             double x = wsum[0];
             for (int k = 1; k < SOLVE_THREADS / WAVE; k++) x += wsum[k];
@@ -470,6 +470,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
                     if (bits != TOTAL_SENTINEL) break;
                     __builtin_amdgcn_s_sleep(2);
                 }
+                if (bits == TOTAL_SENTINEL) sp.ps->fault = 1;         // never written within the bound
                 v = __longlong_as_double((long long)bits);
                 __hip_atomic_store(slot, TOTAL_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
             }

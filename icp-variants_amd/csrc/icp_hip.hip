@@ -951,6 +951,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     HIPCK(c, hipStreamSynchronize(c->stream));
     memcpy(hs.data(), (char*)c->pinned + pin_stats, (size_t)iters * sizeof(icp_iter_stats));
     memcpy(pose_inout, ((const PoseState*)((char*)c->pinned + pin_pose))->pose, 64);
+    if (((const PoseState*)((char*)c->pinned + pin_pose))->fault) { c->err = "reduction hand-over timed out on the device (k_reduce_solve)"; return ICP_ERR_HIP; }
     int status = ICP_OK;
     for (int i = 0; i < iters; i++) {
         if (ns[i] <= 0) { hs[i].n_src = 0; hs[i].n_valid = 0; hs[i].status = ICP_ERR_NO_CORRESPONDENCES; memcpy(hs[i].pose, i ? hs[i - 1].pose : pose_in, 64); hs[i].rmse = -1.f; hs[i].benchmark_error = -1.f; }
