@@ -695,6 +695,168 @@ __device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, cons
     if (kp.d2_out) kp.d2_out[k] = best;
 }
 
+#ifndef ICP_SHARE_WALKS
+#define ICP_SHARE_WALKS 1        // 1: the lanes of a wave that have nothing (left) to search take pending subtrees off the lanes that still walk
+#endif
+#ifndef ICP_SHARE_ROUNDS
+#define ICP_SHARE_ROUNDS 2
+#endif
+#ifndef ICP_SHARE_INNER
+#define ICP_SHARE_INNER 2
+#endif
+#ifndef ICP_SHARE_DEEP
+#define ICP_SHARE_DEEP 0
+#endif
+#define ICP_SHARE_ROWS 10        // LDS rows (of NT uint2) the shared walk needs per wave
+// The walks of one wave, shared.  A wave lasts as long as its longest walk while the lanes whose queries verified, or whose
+// walks ended early, idle.  Here an idle lane adopts a parked subtree -- the SHALLOWEST pending sibling of a lane that still walks
+// -- together with that lane's query and running best, searches it with the same code, and folds what it found into the owner's
+// record in LDS: (distance, index) by a 64-bit atomic minimum (= the lexicographic minimum the lone walk computes), the bounds
+// on all other points by 32-bit atomic minima of their bit patterns.  Every subtree is still searched by exactly one lane against
+// a bound that is at least the final distance, so the result is the same exact neighbour; only the bounds used by NEXT iteration's
+// verify test may differ (conservatively).  A query whose walk was shared gets no out-of-leaf bound (second tier off for it).
+// Rows of the wave's LDS slots: 0 key, 1 (others, skipped bound), 2 (out-of-leaf, position), 3-5 and 7-9 the lanes' own results,
+// query and normal parked meanwhile (so that a helper needs no registers of its own for them), 6 the donors' lane numbers.
+template <int DIM, int NT>
+__device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* p, float* keep3, bool need_walk, float& best, int& bi, int& bpos, float& lb_others, float& lb_outleaf,
+                                                uint2* __restrict__ lbq, int tid) {
+    const int lane = tid & 63, Lq = bv.Lq;
+    uint2* R = lbq + (tid & ~63);
+    constexpr unsigned int FMAXB = 0x7F7FFFFFu, NONE = 0x7F800000u;
+    unsigned long long* keys = (unsigned long long*)R;                    // keys[l]
+    R[3 * NT + lane] = make_uint2(__float_as_uint(best), (unsigned int)bi);
+    R[4 * NT + lane] = make_uint2((unsigned int)bpos, __float_as_uint(lb_others));
+    R[5 * NT + lane] = make_uint2(__float_as_uint(lb_outleaf), __float_as_uint(p[0]));
+    R[7 * NT + lane] = make_uint2(__float_as_uint(p[1]), __float_as_uint(p[2]));
+    R[8 * NT + lane] = make_uint2(__float_as_uint(keep3[0]), __float_as_uint(keep3[1]));
+    R[9 * NT + lane] = make_uint2(__float_as_uint(keep3[2]), 0u);
+    keys[lane] = ~0ull;
+    R[1 * NT + lane] = make_uint2(FMAXB, FMAXB);
+    R[2 * NT + lane] = make_uint2(FMAXB, 0xFFFFFFFFu);
+    QueryPt<DIM> qp;
+    make_query<DIM>(bv, p, qp);
+    float wb = best; int wi = bi, wp = bpos;
+    unsigned int touched = 0u;
+    if (need_walk) {
+        if (ICP_SEED_DESCENT && wp < 0) {                                 // first iteration: a greedy descent yields a real candidate (see knn_walk)
+            int idx = 0;
+            for (int L = 0; L < Lq; L++) {
+                f2 l01, l23;
+                quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * L)) - 1u)) + (unsigned int)idx, qp, l01, l23);
+                const float m = fminf(fminf(l01.x, l01.y), fminf(l23.x, l23.y));
+                const int c = (l01.x == m) ? 0 : (l01.y == m) ? 1 : (l23.x == m) ? 2 : 3;
+                idx = (idx << 2) | c;
+            }
+            float unused = FLT_MAX, unused2 = FLT_MAX;
+            leaf_eval<DIM>(bv.leaves + idx, idx, qp.p2, wb, wi, wp, unused, unused2);
+        }
+        if (ICP_PREFETCH_PATH && wp >= 0) touched = quad_prefetch_path<DIM>(bv, wp >> 3);
+    }
+    float b2 = FLT_MAX, o2 = FLT_MAX;
+    unsigned int mlb = FMAXB;
+    int owner = need_walk ? lane : -1;                                    // whose query this lane is searching for; -1: idle
+    QuadStateT<unsigned int> st; st.L = 0; st.idx = 0; st.pending = 0u; st.alive = need_walk;
+    float thr = fminf(wb * 1.00002f, FLT_MAX);
+    for (;;) {
+        if (!st.alive && owner >= 0) {
+            // this lane's (part of the) search is over: fold it into the owner's record
+            const unsigned long long mykey = ((unsigned long long)__float_as_uint(wb) << 32) | (unsigned int)wi;
+            const unsigned long long old = __hip_atomic_fetch_min(keys + owner, mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            unsigned int* om = (unsigned int*)(R + 1 * NT + owner);       // {others, skipped}
+            unsigned int* op = (unsigned int*)(R + 2 * NT + owner);       // {out of leaf, position}
+            // whoever of the two candidates is not the minimum is an "other" point (the record's initial key stands for none)
+            const unsigned int loser = old == mykey ? FMAXB : old < mykey ? __float_as_uint(wb) : old == ~0ull ? FMAXB : (unsigned int)(old >> 32);
+            __hip_atomic_fetch_min(om, min(loser, __float_as_uint(b2)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_min(om + 1, mlb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_min(op, owner == lane ? __float_as_uint(o2) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (keys[owner] == mykey) op[1] = (unsigned int)wp;
+            owner = -1;
+        }
+        if (!__any(st.alive)) break;
+        bool served = true;                                               // wave-uniform: no idle lane is left without work
+#pragma unroll 1
+        for (int round = 0; round < ICP_SHARE_ROUNDS; round++) {
+            const unsigned long long im = __ballot(owner < 0);
+            if (!im) break;
+            const bool can = st.alive && st.pending != 0u;
+            const unsigned long long dm = __ballot(can);
+            served = __popcll(im) <= __popcll(dm);
+            if (!dm) break;
+            {
+                const int n = min(__popcll(im), __popcll(dm));
+                int* tbl = (int*)(R + 6 * NT);
+                int dL = 0, dIdx = 0;
+                const int rd = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)dm, 0u));      // donors below me
+                if (can && rd < n) {
+                    const int low = ICP_SHARE_DEEP ? 31 - __clz((int)st.pending) : __ffs((int)st.pending) - 1;            // shallowest parked child: the largest subtree
+                    const int lv = low >> 2;
+                    st.pending &= ~(1u << low);
+                    dL = lv + 1; dIdx = ((st.idx >> (2 * (st.L - lv))) << 2) | (low & 3);
+                    tbl[rd] = lane;
+                }
+                const int ri = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(im >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)im, 0u));
+                const bool take = owner < 0 && ri < n;
+                const int src = take ? tbl[ri] : lane;
+                float q[DIM];
+#pragma unroll
+                for (int a = 0; a < DIM; a++) q[a] = __shfl(qp.p2[a].x, src, WAVE);
+                const float sb = __shfl(wb, src, WAVE); const int si = __shfl(wi, src, WAVE), sp = __shfl(wp, src, WAVE), so = __shfl(owner, src, WAVE);
+                const int sL = __shfl(dL, src, WAVE), sI = __shfl(dIdx, src, WAVE);
+                if (take) {
+#pragma unroll
+                    for (int a = 0; a < DIM; a++) { qp.p2[a].x = q[a]; qp.p2[a].y = q[a]; }
+                    wb = sb; wi = si; wp = sp; owner = so;
+                    b2 = FLT_MAX; o2 = FLT_MAX; mlb = FMAXB;
+                    thr = fminf(wb * 1.00002f, FLT_MAX);
+                    st.L = sL; st.idx = sI; st.pending = 0u; st.alive = true;
+                }
+            }
+        }
+        while (st.alive && st.L < Lq) {
+            f2 l01, l23;
+            quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * st.L)) - 1u)) + (unsigned int)st.idx, qp, l01, l23);
+            const float m = fminf(fminf(l01.x, l01.y), fminf(l23.x, l23.y));
+            const bool s0 = !(l01.x > thr), s1 = !(l01.y > thr), s2 = !(l23.x > thr), s3 = !(l23.y > thr);
+            mlb = min(min(mlb, min(s0 ? NONE : __float_as_uint(l01.x), s1 ? NONE : __float_as_uint(l01.y))), min(s2 ? NONE : __float_as_uint(l23.x), s3 ? NONE : __float_as_uint(l23.y)));
+            if (!(m > thr)) {
+                const bool b0 = l01.x == m, b1 = l01.y == m, bb2 = l23.x == m;
+                int c = 3; c = bb2 ? 2 : c; c = b1 ? 1 : c; c = b0 ? 0 : c;
+                const unsigned int pend = ((s0 ? 1u : 0u) | (s1 ? 2u : 0u) | (s2 ? 4u : 0u) | (s3 ? 8u : 0u)) & ~(1u << c);
+                st.pending |= pend << (4 * st.L);
+                st.idx = (st.idx << 2) | c; st.L++;
+            } else st.alive = false;
+            quad_pop_bits(st);
+            // a lane just ran out of work: back to the hand-over at once -- unless lanes idle already, i.e. parked subtrees are what is
+            // scarce (ICP_SHARE_INNER 2; 1 = always)
+            if (ICP_SHARE_INNER && (ICP_SHARE_INNER == 1 || served) && __any(!st.alive)) break;
+        }
+        if (st.alive && st.L == Lq) {                                      // (a lane that left the loop above early is still at a node)
+            leaf_eval<DIM>(bv.leaves + st.idx, st.idx, qp.p2, wb, wi, wp, b2, o2);
+            thr = fminf(wb * 1.00002f, FLT_MAX);
+            st.alive = false;
+            quad_pop_bits(st);
+        }
+    }
+    asm volatile("" ::"v"(touched));
+    {
+        const uint2 c = R[5 * NT + lane], d = R[7 * NT + lane], e = R[8 * NT + lane], f = R[9 * NT + lane];
+        p[0] = __uint_as_float(c.y); p[1] = __uint_as_float(d.x); p[2] = __uint_as_float(d.y);
+        keep3[0] = __uint_as_float(e.x); keep3[1] = __uint_as_float(e.y); keep3[2] = __uint_as_float(f.x);
+    }
+    if (need_walk) {
+        const unsigned long long key = keys[lane];
+        const uint2 a = R[1 * NT + lane], b = R[2 * NT + lane];
+        best = __uint_as_float((unsigned int)(key >> 32)); bi = (int)(unsigned int)key; bpos = (int)b.y;
+        const float sk = __uint_as_float(a.y);
+        lb_others = sqrtf(fminf(__uint_as_float(a.x), sk)) * 0.999999f;
+        lb_outleaf = sqrtf(fminf(__uint_as_float(b.x), sk)) * 0.999999f;
+    } else {
+        const uint2 a = R[3 * NT + lane], b = R[4 * NT + lane], c = R[5 * NT + lane];
+        best = __uint_as_float(a.x); bi = (int)a.y; bpos = (int)b.x; lb_others = __uint_as_float(b.y); lb_outleaf = __uint_as_float(c.x);
+    }
+}
+
+
 // ---- wave-cooperative search of ONE query -----------------------------------------------------------------------------
 // Once ICP has converged almost every query is verified without a walk; the few that are not (and the far-away queries with
 // long walks in general) then decide how long the kernel runs: a lone lane pays ~0.3 us per dependent step for 30-50 steps

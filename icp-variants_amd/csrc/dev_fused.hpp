@@ -129,10 +129,24 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
             const float rb = __shfl(b, from, WAVE), rl = __shfl(lbo, from, WAVE), rl2 = __shfl(lbo2, from, WAVE); const int ri = __shfl(ci, from, WAVE), rp = __shfl(cps, from, WAVE);
             const bool rdone = __shfl((int)done, from, WAVE) != 0;
             if (need_walk && rdone) { best = rb; bi = ri; bpos = rp; lb_others = rl; lb_outleaf = rl2; need_walk = false; }
+#if ICP_SHARE_WALKS
+            q0 = -2;
+#endif
         }
     }
 #if ICP_DEBUG_STEPS
     if (k >= 0 && kp.dbg_steps) kp.dbg_steps[k] = need_walk ? -1 : leaf_only ? -2 : 0;      // -1: walk (overwritten with its length); -2: second tier, one leaf
+#endif
+#if ICP_SHARE_WALKS
+    if (bv.Lq > 0 && bv.Lq <= 8) {
+        if (__any(need_walk)) {
+            float rn[3] = {rn0, rn1, rn2};
+            knn_walk_shared<DIM, BVH_THREADS>(bv, p, rn, need_walk, best, bi, bpos, lb_others, lb_outleaf, bvh_lbq, tid);
+            rn0 = rn[0]; rn1 = rn[1]; rn2 = rn[2];
+            q0 = -2;                                      // the neighbour's record is read again below: it need not stay in registers while this lane helps
+        }
+    }
+    else
 #endif
     if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lb_outleaf, bvh_lbq, tid, (ICP_DEBUG_STEPS && kp.dbg_steps) ? kp.dbg_steps + k : nullptr);
     if (k >= 0) {

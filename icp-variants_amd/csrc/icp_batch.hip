@@ -87,8 +87,22 @@ thread_local std::string g_err;
 bool load_rccl() {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_rccl.h) return true;
-    // a copy that the process already holds (e.g. the one PyTorch ships) wins: two RCCL instances in one process are asking for trouble
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    // The RCCL to use is the one that sits next to the HIP runtime THIS library is bound to: its communicators must see the streams
+    // and buffers created here.  A process can hold two ROCm stacks -- PyTorch wheels ship their own libamdhip64 / libhsa-runtime64 /
+    // librccl: imported first, its libamdhip64 (soname libamdhip64.so.7) also serves this library; imported second, it comes on top of
+    // the system stack this library already pulled in -- and an RCCL on the other stack finds "no ROCm-capable device".
+    void* h = nullptr;
+    Dl_info di;
+    if (dladdr((const void*)&hipGetDeviceCount, &di) && di.dli_fname) {
+        std::string dir(di.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash + 1);
+            h = dlopen((dir + "librccl.so.1").c_str(), RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen((dir + "librccl.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
+        }
+    }
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);

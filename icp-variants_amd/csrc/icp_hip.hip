@@ -426,7 +426,7 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
     BvhViewT<DIM> bv; bv.leaves = b.leaves.as<BvhLeafT<DIM>>(); bv.nodes = b.nodes.as<BvhNodeT<DIM>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
     bv.qnodes = b.qnodes.as<BvhQuadT<DIM>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>();
     const int nb = (n + BVH_THREADS - 1) / BVH_THREADS;
-    const size_t stack_bytes = (size_t)(b.Lq > 0 ? b.Lq : 1) * BVH_THREADS * 8;
+    const size_t stack_bytes = (size_t)(b.Lq > (ICP_SHARE_WALKS ? ICP_SHARE_ROWS : 1) ? b.Lq : (ICP_SHARE_WALKS ? ICP_SHARE_ROWS : 1)) * BVH_THREADS * 8;
     if (fuse) {
         if ((rc = ensure(c, c->partials, (size_t)(nb > POST_BLOCKS ? nb : POST_BLOCKS) * NSUM * 8))) return rc;
         PostParams pp = make_post_params(c, *fuse, kp.sel, n);

@@ -231,3 +231,21 @@ def test_iteration_times_and_params_validation(gpu_ctx_factory, bunny):
             c.push_params()
         setattr(c.params, field, keep)
     c.push_params()
+
+
+@pytest.mark.parametrize("order", ["binding_first", "torch_first", "binding_only"])
+def test_comm_finds_the_rccl_of_its_own_hip_runtime(order):
+    """PyTorch wheels ship a second ROCm stack (libamdhip64, libhsa-runtime64, librccl).  Whichever of torch / this library a process
+    imports first, icp_comm_create has to load the RCCL that belongs to the HIP runtime libicp_hip.so is bound to (a fresh process
+    per order: the loader state is the thing under test)."""
+    import subprocess, sys
+    imports = {"binding_first": "from icp_amd import binding; import torch", "torch_first": "import torch; from icp_amd import binding",
+               "binding_only": "from icp_amd import binding"}[order]
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); %s\n"
+            "c = binding.Context(0)\n"
+            "comm = binding.Comm(0, 1, 0, binding.Comm.unique_id())\n"
+            "p = np.arange(32, dtype=np.float32).reshape(2, 16)\n"
+            "assert np.array_equal(comm.gather_poses(p, 2), p)\n"
+            "comm.close(); print('gathered')\n") % (os.path.join(ROOT, "icp-variants_amd", "python"), imports)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "gathered" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
