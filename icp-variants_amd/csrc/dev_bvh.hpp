@@ -1,4 +1,4 @@
-// dev_bvh.hpp -- exact kd-ordered BVH: build kernels, 4-wide nodes, walk, cooperative search, k_knn_bvh.
+// dev_bvh.hpp -- exact kd-ordered BVH: build kernels, 4-wide nodes, the walk (per lane, and shared over the wave), k_knn_bvh.
 // Part of icp_device.hpp (included from there, inside namespace icpdev); see that file for the build contract.
 // ------------------------------------------------------------------------------------------------
 // Exact kd-ordered BVH 1-NN: the index the reference builds once per pair (NearestNeighbor.h:122-141 / :209-232, a FLANN
@@ -22,10 +22,6 @@
 #endif
 #ifndef ICP_SEED_DESCENT
 #define ICP_SEED_DESCENT 1
-#endif
-#ifndef ICP_COOP_MAX
-#define ICP_COOP_MAX 16         // a wave with at most this many (seeded) queries left to search does them cooperatively, one per lane group; 0 = never
-                                // (measured, iterations 10-16: 2 one after the other 0.0424 ms, 8 at once 0.0382, 16 at once 0.0334)
 #endif
 #ifndef ICP_PREFETCH_PATH
 #define ICP_PREFETCH_PATH 1
@@ -699,13 +695,7 @@ __device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, cons
 #define ICP_SHARE_WALKS 1        // 1: the lanes of a wave that have nothing (left) to search take pending subtrees off the lanes that still walk
 #endif
 #ifndef ICP_SHARE_ROUNDS
-#define ICP_SHARE_ROUNDS 2
-#endif
-#ifndef ICP_SHARE_INNER
-#define ICP_SHARE_INNER 2
-#endif
-#ifndef ICP_SHARE_DEEP
-#define ICP_SHARE_DEEP 0
+#define ICP_SHARE_ROUNDS 2       // hand-over rounds per pass (each pairs the idle lanes with as many donors, one subtree per donor)
 #endif
 #define ICP_SHARE_ROWS 10        // LDS rows (of NT uint2) the shared walk needs per wave
 // The walks of one wave, shared.  A wave lasts as long as its longest walk while the lanes whose queries verified, or whose
@@ -717,7 +707,7 @@ __device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, cons
 // verify test may differ (conservatively).  A query whose walk was shared gets no out-of-leaf bound (second tier off for it).
 // Rows of the wave's LDS slots: 0 key, 1 (others, skipped bound), 2 (out-of-leaf, position), 3-5 and 7-9 the lanes' own results,
 // query and normal parked meanwhile (so that a helper needs no registers of its own for them), 6 the donors' lane numbers.
-template <int DIM, int NT>
+template <int DIM, int NT, class MaskT>
 __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* p, float* keep3, bool need_walk, float& best, int& bi, int& bpos, float& lb_others, float& lb_outleaf,
                                                 uint2* __restrict__ lbq, int tid) {
     const int lane = tid & 63, Lq = bv.Lq;
@@ -755,7 +745,7 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
     float b2 = FLT_MAX, o2 = FLT_MAX;
     unsigned int mlb = FMAXB;
     int owner = need_walk ? lane : -1;                                    // whose query this lane is searching for; -1: idle
-    QuadStateT<unsigned int> st; st.L = 0; st.idx = 0; st.pending = 0u; st.alive = need_walk;
+    QuadStateT<MaskT> st; st.L = 0; st.idx = 0; st.pending = 0; st.alive = need_walk;
     float thr = fminf(wb * 1.00002f, FLT_MAX);
     for (;;) {
         if (!st.alive && owner >= 0) {
@@ -778,7 +768,7 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
         for (int round = 0; round < ICP_SHARE_ROUNDS; round++) {
             const unsigned long long im = __ballot(owner < 0);
             if (!im) break;
-            const bool can = st.alive && st.pending != 0u;
+            const bool can = st.alive && st.pending != 0;
             const unsigned long long dm = __ballot(can);
             served = __popcll(im) <= __popcll(dm);
             if (!dm) break;
@@ -788,9 +778,9 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
                 int dL = 0, dIdx = 0;
                 const int rd = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)dm, 0u));      // donors below me
                 if (can && rd < n) {
-                    const int low = ICP_SHARE_DEEP ? 31 - __clz((int)st.pending) : __ffs((int)st.pending) - 1;            // shallowest parked child: the largest subtree
+                    const int low = sizeof(MaskT) == 8 ? __ffsll((long long)st.pending) - 1 : __ffs((int)st.pending) - 1;            // shallowest parked child: the largest subtree
                     const int lv = low >> 2;
-                    st.pending &= ~(1u << low);
+                    st.pending &= ~((MaskT)1 << low);
                     dL = lv + 1; dIdx = ((st.idx >> (2 * (st.L - lv))) << 2) | (low & 3);
                     tbl[rd] = lane;
                 }
@@ -808,7 +798,7 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
                     wb = sb; wi = si; wp = sp; owner = so;
                     b2 = FLT_MAX; o2 = FLT_MAX; mlb = FMAXB;
                     thr = fminf(wb * 1.00002f, FLT_MAX);
-                    st.L = sL; st.idx = sI; st.pending = 0u; st.alive = true;
+                    st.L = sL; st.idx = sI; st.pending = 0; st.alive = true;
                 }
             }
         }
@@ -822,13 +812,14 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
                 const bool b0 = l01.x == m, b1 = l01.y == m, bb2 = l23.x == m;
                 int c = 3; c = bb2 ? 2 : c; c = b1 ? 1 : c; c = b0 ? 0 : c;
                 const unsigned int pend = ((s0 ? 1u : 0u) | (s1 ? 2u : 0u) | (s2 ? 4u : 0u) | (s3 ? 8u : 0u)) & ~(1u << c);
-                st.pending |= pend << (4 * st.L);
+                st.pending |= (MaskT)pend << (4 * st.L);
                 st.idx = (st.idx << 2) | c; st.L++;
             } else st.alive = false;
             quad_pop_bits(st);
-            // a lane just ran out of work: back to the hand-over at once -- unless lanes idle already, i.e. parked subtrees are what is
-            // scarce (ICP_SHARE_INNER 2; 1 = always)
-            if (ICP_SHARE_INNER && (ICP_SHARE_INNER == 1 || served) && __any(!st.alive)) break;
+            // Back to the hand-over as soon as it has something to do: while every idle lane found work last time (lanes are what is
+            // scarce) when a lane runs out of work; otherwise (lanes idle, parked subtrees scarce) when a lane parks one.  Measured against
+            // handing over only between leaves: iteration 0 0.142 -> 0.126 ms, iterations 1-9 0.065 -> 0.061, 10-16 0.033 -> 0.028.
+            if (served ? __any(!st.alive) : __any(st.pending != 0)) break;
         }
         if (st.alive && st.L == Lq) {                                      // (a lane that left the loop above early is still at a node)
             leaf_eval<DIM>(bv.leaves + st.idx, st.idx, qp.p2, wb, wi, wp, b2, o2);
@@ -857,16 +848,6 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
 }
 
 
-// ---- wave-cooperative search of ONE query -----------------------------------------------------------------------------
-// Once ICP has converged almost every query is verified without a walk; the few that are not (and the far-away queries with
-// long walks in general) then decide how long the kernel runs: a lone lane pays ~0.3 us per dependent step for 30-50 steps
-// while 63 lanes idle.  Here the whole wave searches for that one query: level-synchronous over the 4-wide tree, one frontier
-// node per lane (all four child boxes against the SEED bound, survivors compacted with ballots into the next frontier), then
-// one leaf per lane, then a lexicographic wave minimum -- about Lq + 2 dependent steps instead of the length of the walk.
-// Same prune rule and same leaf evaluation as the per-lane walk, hence the same exact (d2, lowest index) result; the bound
-// on all other targets comes out the same way (smallest skipped box bound / evaluated non-winner).  The frontier lives in the
-// wave's own (idle) stack slots: .x / .y of the uint2 slots are the two buffers, Lq * 64 entries each.
-// Returns false (outputs untouched) when a frontier would overflow -> the caller falls back to the per-lane walk.
 __device__ __forceinline__ float wave_min_f32(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, WAVE));
@@ -876,90 +857,6 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, WAVE));
     return v;
-}
-// Generalised to GROUPS of lanes: the wave is split into G = 64 / S aligned groups of S lanes (S = 64, 32, 16 or 8) and every
-// group searches ONE query, all groups at once.  A wave with up to 8 unverified queries finishes them in about Lq + 2 dependent
-// steps instead of the longest of their walks (20-50 steps): once most queries verify, these few walks are what an iteration waits
-// for.  Per group: own frontier in its share of the wave's stack slots (Lq * S entries per buffer), ballots masked to the group's
-// lanes, group-wide minima by xor-shuffles that stay inside the aligned group.  gact: this lane's group has a query; q, best, bi,
-// bpos: that query and its seed, identical in all lanes of the group.  Returns (per lane, uniform in the group) whether the search
-// completed; false (outputs untouched) when the group's frontier would overflow -> that query falls back to the per-lane walk.
-template <int DIM, int NT>
-__device__ __forceinline__ bool coop_search(const BvhViewT<DIM>& bv, const float* q, bool gact, int lgS, float& best, int& bi, int& bpos, float& lb_others, float& lb_outleaf,
-                                            uint2* __restrict__ lbq, int tid) {
-    const int lane = tid & 63, wbase = tid & ~63;          // this wave's slots: lbq[row * NT + wbase + col]
-    const int S = 1 << lgS, gl = lane & (S - 1), g = lane >> lgS;
-    const unsigned long long gm = (lgS == 6 ? ~0ull : ((1ull << S) - 1ull)) << (g * S);          // the lanes of my group
-    const unsigned long long lt = gm & ((1ull << lane) - 1ull);                                   // ... below me
-    const int Lq = bv.Lq, cap = Lq << lgS;                 // entries per buffer and group
-    QueryPt<DIM> qp;
-    make_query<DIM>(bv, q, qp);
-    const float thr = fminf(best * 1.00002f, FLT_MAX);
-    float minlb = FLT_MAX;
-    unsigned int* slot = (unsigned int*)lbq;               // entry E of buffer b: slot[2 * ((E >> 6) * NT + wbase + (E & 63)) + b]; group g owns E in [g * cap, (g + 1) * cap)
-    const int e0 = g * cap;
-    int n = gact ? 1 : 0, cur = 0;
-    bool ok = gact;
-    if (gl == 0 && gact) slot[2 * ((e0 >> 6) * NT + wbase + (e0 & 63)) + 0] = 0u;
-    for (int L = 0; L < Lq; L++) {
-        int nn = 0;                                        // group-uniform size of the next frontier
-        for (int base = 0; __any(ok && base < n); base += S) {
-            const int e = base + gl;
-            const bool act = ok && e < n;
-            const int E = e0 + e;
-            const unsigned int node = act ? slot[2 * ((E >> 6) * NT + wbase + (E & 63)) + cur] : 0u;
-            f2 l01, l23;
-            quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * L)) - 1u)) + node, qp, l01, l23);
-            const bool s0 = act && !(l01.x > thr), s1 = act && !(l01.y > thr), s2 = act && !(l23.x > thr), s3 = act && !(l23.y > thr);
-            if (act) minlb = fminf(minlb, fminf(fminf(s0 ? FLT_MAX : l01.x, s1 ? FLT_MAX : l01.y), fminf(s2 ? FLT_MAX : l23.x, s3 ? FLT_MAX : l23.y)));
-            const unsigned long long m0 = __ballot(s0) & gm, m1 = __ballot(s1) & gm, m2 = __ballot(s2) & gm, m3 = __ballot(s3) & gm;
-            const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), c3 = __popcll(m3);
-            if (nn + c0 + c1 + c2 + c3 > cap) ok = false;                                     // uniform in the group: it gives up
-            const int o0 = nn + __popcll(m0 & lt), o1 = nn + c0 + __popcll(m1 & lt), o2 = nn + c0 + c1 + __popcll(m2 & lt), o3 = nn + c0 + c1 + c2 + __popcll(m3 & lt);
-            const unsigned int ch = node << 2;
-            if (ok) {
-                if (s0) { const int F = e0 + o0; slot[2 * ((F >> 6) * NT + wbase + (F & 63)) + (cur ^ 1)] = ch; }
-                if (s1) { const int F = e0 + o1; slot[2 * ((F >> 6) * NT + wbase + (F & 63)) + (cur ^ 1)] = ch | 1u; }
-                if (s2) { const int F = e0 + o2; slot[2 * ((F >> 6) * NT + wbase + (F & 63)) + (cur ^ 1)] = ch | 2u; }
-                if (s3) { const int F = e0 + o3; slot[2 * ((F >> 6) * NT + wbase + (F & 63)) + (cur ^ 1)] = ch | 3u; }
-            }
-            nn += c0 + c1 + c2 + c3;
-        }
-        n = nn; cur ^= 1;
-        if (!__any(ok && n > 0)) break;
-    }
-    // leaves: one per lane and round; every lane starts from its group's seed
-    float b = best, b2 = FLT_MAX, o2 = FLT_MAX; int i = bi, ps = bpos;
-    for (int base = 0; __any(ok && base < n); base += S) {
-        const int e = base + gl;
-        if (ok && e < n) {
-            const int E = e0 + e;
-            const int leaf = (int)slot[2 * ((E >> 6) * NT + wbase + (E & 63)) + cur];
-            leaf_eval<DIM>(bv.leaves + leaf, leaf, qp.p2, b, i, ps, b2, o2);
-        }
-    }
-    // minima over the group (xor-shuffles below S stay inside the aligned group)
-    float wb = b;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(wb, o, WAVE); if (o < S) wb = fminf(wb, t); }
-    int wi = (b == wb) ? i : 0x7FFFFFFF;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(wi, o, WAVE); if (o < S) wi = min(wi, t); }
-    const bool mine = (b == wb) && (i == wi);             // lanes holding the winner (several if it is the seed)
-    const unsigned long long mm = __ballot(mine) & gm;
-    const int wl = __ffsll((long long)mm) - 1;
-    const int wps = __shfl(ps, wl < 0 ? lane : wl, WAVE);
-    float others = mine ? b2 : fminf(b, b2);              // a lane whose local winner lost: that point is an "other" too
-    // ... and it lies outside the winner's leaf unless it sits in that very leaf (a lane that kept the seed while another lane found
-    // the winner in the seed's leaf); every leaf is evaluated by one lane only, so a lane's o2 never holds points of the winner's leaf
-    float outl = fminf(o2, (!mine && (ps >> 3) != (wps >> 3)) ? b : FLT_MAX);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float t = __shfl_xor(others, o, WAVE), u = __shfl_xor(minlb, o, WAVE), v = __shfl_xor(outl, o, WAVE);
-        if (o < S) { others = fminf(others, t); minlb = fminf(minlb, u); outl = fminf(outl, v); }
-    }
-    if (ok) { best = wb; bi = wi; bpos = wps; lb_others = sqrtf(fminf(others, minlb)) * 0.999999f; lb_outleaf = sqrtf(fminf(outl, minlb)) * 0.999999f; }
-    return ok;
 }
 
 // The tree walk proper for query p, starting from the seed (best, bi, bpos); returns the lower bound on the distance to every
@@ -1002,19 +899,32 @@ __device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* 
     return sqrtf(fminf(best2, minlb)) * 0.999999f;
 }
 
+// One query per lane (k < 0: none), the whole wave together: the lanes without a walk of their own help with the others'.
 template <int DIM>
 __device__ __forceinline__ void knn_bvh_query(const KnnParams& kp, const BvhViewT<DIM>& bv, int k, uint2* __restrict__ lbq, int tid,
                                               float& best, int& bi, int& bpos) {
     float p[DIM];
-    knn_load_query<DIM>(kp, k, p);
+#pragma unroll
+    for (int q = 0; q < DIM; q++) p[q] = 0.f;
+    if (k >= 0) knn_load_query<DIM>(kp, k, p);
     best = FLT_MAX; bi = -1; bpos = -1;
     float lb_others = 0.f, lb_outleaf = 0.f;      // lower bounds on the (real) distance from p to every target except bi / outside bi's leaf
-    if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
+    bool need_walk = false;
+    if (k >= 0 && finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
         // (a query verified here re-anchors; its leaf bound shrinks by the same step: lb_others is already L - delta)
         if (knn_try_verify<DIM>(kp, bv, k, p, best, bi, bpos, lb_others)) lb_outleaf = lb_others;
-        else lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lb_outleaf, lbq, tid);
+        else need_walk = true;
     }
-    knn_store_state<DIM>(kp, k, p, best, bpos, lb_others, lb_outleaf);
+#if ICP_SHARE_WALKS
+    if (__any(need_walk)) {
+        float none[3] = {0.f, 0.f, 0.f};
+        if (bv.Lq <= 8) knn_walk_shared<DIM, BVH_THREADS, unsigned int>(bv, p, none, need_walk, best, bi, bpos, lb_others, lb_outleaf, lbq, tid);
+        else knn_walk_shared<DIM, BVH_THREADS, unsigned long long>(bv, p, none, need_walk, best, bi, bpos, lb_others, lb_outleaf, lbq, tid);
+    }
+#else
+    if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lb_outleaf, lbq, tid);
+#endif
+    if (k >= 0) knn_store_state<DIM>(kp, k, p, best, bpos, lb_others, lb_outleaf);
 }
 
 // Which query does this lane serve?  Position t of the (Morton-sorted) query order, in XCD-contiguous slices.
@@ -1026,12 +936,12 @@ __device__ __forceinline__ int knn_bvh_lane_query(const KnnParams& kp, const int
 
 template <int DIM>
 __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder) {
-    extern __shared__ uint2 bvh_lbq[];                    // [Lq][BVH_THREADS] pending-sibling bounds
+    extern __shared__ uint2 bvh_lbq[];                    // [ICP_SHARE_ROWS][BVH_THREADS]: the shared walk's records
     const int tid = threadIdx.x;
     const int k = knn_bvh_lane_query(kp, qorder, tid);
-    if (k < 0) return;
     float best; int bi, bpos;
     knn_bvh_query<DIM>(kp, bv, k, bvh_lbq, tid, best, bi, bpos);
+    if (k < 0) return;
     icp_match_t m;
     if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
     kp.out[k] = m;

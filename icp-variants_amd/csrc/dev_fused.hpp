@@ -33,9 +33,9 @@ struct P2pGen {                                           // values 0..21 = sum 
 // query, a stable 8-class rank in the epilogue): iterations 1-9 0.084 vs 0.079 ms -- the prediction is not worth the extra dependent
 // load in front of everything and the gathers.  What did pay was making k_reduce_solve itself cheaper (one load
 // round, fence-free hand-over): see dev_solve.hpp.
-template <int DIM>
+template <int DIM, bool WIDE>      // WIDE: trees deeper than 8 levels of 4-wide nodes (> 524 288 targets) keep 64 pending bits per lane
 __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {
-    extern __shared__ uint2 bvh_lbq[];                    // [Lq][BVH_THREADS] pending-sibling bounds; reused by the reduction
+    extern __shared__ uint2 bvh_lbq[];                    // [ICP_SHARE_ROWS][BVH_THREADS]: the shared walk's records; reused by the reduction
     constexpr int NW = BVH_THREADS / WAVE;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int t0 = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS;
@@ -104,51 +104,23 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
         lb_others = fminf(sqrtf(b2) * 0.999999f, lb_outleaf);                           // re-anchored here: second best of the leaf, or anything outside it
         need_walk = false;
     }
-    // ---- the walks.  A wave left with at most ICP_COOP_MAX seeded queries to search does them cooperatively, all at once, one per
-    // group of lanes (coop_search); otherwise every lane walks on its own.
-    {
-        const unsigned long long wm = __ballot(need_walk);
-        const unsigned long long cm = __ballot(need_walk && bpos >= 0);
-        const int W = __popcll(wm);
-        static_assert(ICP_COOP_MAX <= 16, "at most 16 lane groups");
-        if (ICP_COOP_MAX > 0 && W > 0 && wm == cm && W <= ICP_COOP_MAX && bv.Lq > 0) {
-            const int lgS = W == 1 ? 6 : W == 2 ? 5 : W <= 4 ? 4 : W <= 8 ? 3 : 2;     // 1 / 2 / 4 / 8 / 16 groups of 64 / 32 / 16 / 8 / 4 lanes
-            const int g = lane >> lgS;
-            unsigned long long rest = wm;                                            // source lane of my group: the g-th walker
-            for (int t = 0; t < g && t < 15; t++) rest &= rest - 1ull;
-            const bool gact = g < W;
-            const int src = gact ? __ffsll((long long)rest) - 1 : lane;
-            float q[DIM];
-#pragma unroll
-            for (int a = 0; a < DIM; a++) q[a] = __shfl(p[a], src, WAVE);
-            float b = __shfl(best, src, WAVE), lbo = 0.f, lbo2 = 0.f; int ci = __shfl(bi, src, WAVE), cps = __shfl(bpos, src, WAVE);
-            const bool done = coop_search<DIM, BVH_THREADS>(bv, q, gact, lgS, b, ci, cps, lbo, lbo2, bvh_lbq, tid);
-            // the result travels back to the source lane: it reads it from the first lane of the group that searched for it
-            const int gsrc = __popcll(wm & ((1ull << lane) - 1ull));                 // my rank among the walkers = the group that served me
-            const int from = min(gsrc, 15) << lgS;
-            const float rb = __shfl(b, from, WAVE), rl = __shfl(lbo, from, WAVE), rl2 = __shfl(lbo2, from, WAVE); const int ri = __shfl(ci, from, WAVE), rp = __shfl(cps, from, WAVE);
-            const bool rdone = __shfl((int)done, from, WAVE) != 0;
-            if (need_walk && rdone) { best = rb; bi = ri; bpos = rp; lb_others = rl; lb_outleaf = rl2; need_walk = false; }
-#if ICP_SHARE_WALKS
-            q0 = -2;
-#endif
-        }
-    }
+    // ---- the walks: shared over the wave (knn_walk_shared) -- the lanes whose queries verified, and those whose walks end early, take
+    // parked subtrees off the lanes still searching.  (Until round 2 a wave with <= 16 walkers searched them level-synchronously in lane
+    // groups instead; the shared walk does that case as well, 0.0281 vs 0.0306 ms in iterations 10-16, and the kernel without the second
+    // code path needs 68 instead of 80 VGPRs.)
 #if ICP_DEBUG_STEPS
     if (k >= 0 && kp.dbg_steps) kp.dbg_steps[k] = need_walk ? -1 : leaf_only ? -2 : 0;      // -1: walk (overwritten with its length); -2: second tier, one leaf
 #endif
 #if ICP_SHARE_WALKS
-    if (bv.Lq > 0 && bv.Lq <= 8) {
-        if (__any(need_walk)) {
-            float rn[3] = {rn0, rn1, rn2};
-            knn_walk_shared<DIM, BVH_THREADS>(bv, p, rn, need_walk, best, bi, bpos, lb_others, lb_outleaf, bvh_lbq, tid);
-            rn0 = rn[0]; rn1 = rn[1]; rn2 = rn[2];
-            q0 = -2;                                      // the neighbour's record is read again below: it need not stay in registers while this lane helps
-        }
+    if (__any(need_walk)) {
+        float rn[3] = {rn0, rn1, rn2};
+        knn_walk_shared<DIM, BVH_THREADS, typename std::conditional<WIDE, unsigned long long, unsigned int>::type>(bv, p, rn, need_walk, best, bi, bpos, lb_others, lb_outleaf, bvh_lbq, tid);
+        rn0 = rn[0]; rn1 = rn[1]; rn2 = rn[2];
+        q0 = -2;                                          // the neighbour's record is read again below: it need not stay in registers while this lane helps
     }
-    else
-#endif
+#else
     if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lb_outleaf, bvh_lbq, tid, (ICP_DEBUG_STEPS && kp.dbg_steps) ? kp.dbg_steps + k : nullptr);
+#endif
     if (k >= 0) {
         // A verified query keeps its stored anchor (position of the last full search) and bound: the triangle test stays valid
         // against the OLD anchor -- and is tighter than re-anchoring, (L - d1) - d2 <= L - |d1 + d2| -- and its neighbour is

@@ -426,14 +426,16 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
     BvhViewT<DIM> bv; bv.leaves = b.leaves.as<BvhLeafT<DIM>>(); bv.nodes = b.nodes.as<BvhNodeT<DIM>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
     bv.qnodes = b.qnodes.as<BvhQuadT<DIM>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>();
     const int nb = (n + BVH_THREADS - 1) / BVH_THREADS;
-    const size_t stack_bytes = (size_t)(b.Lq > (ICP_SHARE_WALKS ? ICP_SHARE_ROWS : 1) ? b.Lq : (ICP_SHARE_WALKS ? ICP_SHARE_ROWS : 1)) * BVH_THREADS * 8;
+    const size_t stack_bytes = (size_t)(ICP_SHARE_WALKS ? ICP_SHARE_ROWS : 1) * BVH_THREADS * 8;          // the shared walk's records in LDS
     if (fuse) {
         if ((rc = ensure(c, c->partials, (size_t)(nb > POST_BLOCKS ? nb : POST_BLOCKS) * NSUM * 8))) return rc;
         PostParams pp = make_post_params(c, *fuse, kp.sel, n);
         pp.matches = nullptr;                                                     // the loop never reads the records of a fused iteration
         KnnParams kf = kp; kf.d2_out = nullptr; kf.out = nullptr;                 // ... nor the distances
         const size_t red_bytes = (size_t)(BVH_THREADS / WAVE) * 33 * 8;           // the reduction reuses the (dead) traversal stacks
-        hipLaunchKernelGGL(k_knn_bvh_post<DIM>, dim3(nb), dim3(BVH_THREADS), stack_bytes > red_bytes ? stack_bytes : red_bytes, c->stream, kf, bv, order, pp);
+        const size_t lds = stack_bytes > red_bytes ? stack_bytes : red_bytes;
+        if (b.Lq <= 8) hipLaunchKernelGGL((k_knn_bvh_post<DIM, false>), dim3(nb), dim3(BVH_THREADS), lds, c->stream, kf, bv, order, pp);
+        else hipLaunchKernelGGL((k_knn_bvh_post<DIM, true>), dim3(nb), dim3(BVH_THREADS), lds, c->stream, kf, bv, order, pp);
         *fused_blocks = nb;
     } else {
         hipLaunchKernelGGL(k_knn_bvh<DIM>, dim3(nb), dim3(BVH_THREADS), stack_bytes, c->stream, kp, bv, order);
