@@ -278,6 +278,7 @@ def main():
     ap.add_argument("--n-tilt", type=int, default=344)
     ap.add_argument("--n-beam", type=int, default=1077)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-iteration", action="store_true", help="add the matcher's average device ms per iteration index to per_regime_ms")
     ap.add_argument("--stage-timing", type=int, default=10, help="bracket every Nth ICP iteration of the timed region with HIP events (offset rotates "
                     "from step to step: after N steps every iteration index has been timed once); 1 = every iteration, as the reference's "
                     "TimeMeasure does (costs ~10 %% of an iteration); an event bracket costs ~3 us of stream time")
@@ -430,6 +431,8 @@ def main():
                   "match_iteration_0": regime(0, 1, 0), "match_iterations_1_9": regime(1, 10, 0), "match_iterations_10_16": regime(10, 17, 0),
                   "match_iterations_17_plus": regime(17, args.iterations, 0), "solve_all": regime(0, args.iterations, 1)}
 
+    if args.per_iteration:
+        per_regime["match_by_iteration"] = [round(float(it_sum[0, i] / it_cnt[i]), 5) if it_cnt[i] > 0 else None for i in range(args.iterations)]
     out = {
         "metric": "ICP iterations/s (k-NN + point-to-plane linear, 370k-point ETH-Apartment-like pair)",
         "value": value, "unit": "ICP iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -697,6 +697,9 @@ __device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, cons
 #ifndef ICP_SHARE_ROUNDS
 #define ICP_SHARE_ROUNDS 2       // hand-over rounds per pass (each pairs the idle lanes with as many donors, one subtree per donor)
 #endif
+#ifndef ICP_SHARE_SPREAD
+#define ICP_SHARE_SPREAD 1       // 1: few seeded walkers in a wave -> the levels of their seeds' paths are searched side by side by the idle lanes
+#endif
 #define ICP_SHARE_ROWS 10        // LDS rows (of NT uint2) the shared walk needs per wave
 // The walks of one wave, shared.  A wave lasts as long as its longest walk while the lanes whose queries verified, or whose
 // walks ended early, idle.  Here an idle lane adopts a parked subtree -- the SHALLOWEST pending sibling of a lane that still walks
@@ -740,13 +743,61 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
             float unused = FLT_MAX, unused2 = FLT_MAX;
             leaf_eval<DIM>(bv.leaves + idx, idx, qp.p2, wb, wi, wp, unused, unused2);
         }
-        if (ICP_PREFETCH_PATH && wp >= 0) touched = quad_prefetch_path<DIM>(bv, wp >> 3);
     }
+    // Few walkers, all with a seed: the seed's root-to-leaf path is known, so its Lq nodes need not be visited one after the other.
+    // Every level of every walker's path goes to an idle lane at once (the walker itself takes the seed's leaf): one node step in
+    // parallel instead of Lq dependent ones in front of everything else.  What remains are the off-path children that survive the
+    // seed's bound -- handed on below like any other parked subtree.
+    const unsigned long long wm = __ballot(need_walk);
+    const int W = __popcll(wm);
+    const bool spread = ICP_SHARE_SPREAD && Lq > 0 && W * (Lq + 1) <= WAVE && wm == __ballot(need_walk && wp >= 0);
+    if (ICP_PREFETCH_PATH && !spread && need_walk && wp >= 0) touched = quad_prefetch_path<DIM>(bv, wp >> 3);
     float b2 = FLT_MAX, o2 = FLT_MAX;
     unsigned int mlb = FMAXB;
     int owner = need_walk ? lane : -1;                                    // whose query this lane is searching for; -1: idle
     QuadStateT<MaskT> st; st.L = 0; st.idx = 0; st.pending = 0; st.alive = need_walk;
     float thr = fminf(wb * 1.00002f, FLT_MAX);
+    // one node step on the child bounds of node (st.L, st.idx): nearest surviving child next, the other survivors parked
+    auto descend = [&](const f2& l01, const f2& l23) {
+        const float m = fminf(fminf(l01.x, l01.y), fminf(l23.x, l23.y));
+        const bool s0 = !(l01.x > thr), s1 = !(l01.y > thr), s2 = !(l23.x > thr), s3 = !(l23.y > thr);
+        mlb = min(min(mlb, min(s0 ? NONE : __float_as_uint(l01.x), s1 ? NONE : __float_as_uint(l01.y))), min(s2 ? NONE : __float_as_uint(l23.x), s3 ? NONE : __float_as_uint(l23.y)));
+        if (!(m > thr)) {
+            const bool b0 = l01.x == m, b1 = l01.y == m, bb2 = l23.x == m;
+            int c = 3; c = bb2 ? 2 : c; c = b1 ? 1 : c; c = b0 ? 0 : c;
+            const unsigned int pend = ((s0 ? 1u : 0u) | (s1 ? 2u : 0u) | (s2 ? 4u : 0u) | (s3 ? 8u : 0u)) & ~(1u << c);
+            st.pending |= (MaskT)pend << (4 * st.L);
+            st.idx = (st.idx << 2) | c; st.L++;
+        } else st.alive = false;
+        quad_pop_bits(st);
+    };
+    if (spread) {
+        int* tbl = (int*)(R + 6 * NT);
+        if (need_walk) tbl[__builtin_amdgcn_mbcnt_hi((unsigned int)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)wm, 0u))] = lane;
+        const unsigned long long im = ~wm;
+        const int ri = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(im >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)im, 0u));
+        const int r = (ri * ((65536 + Lq - 1) / Lq)) >> 16, L = ri - r * Lq;           // ri / Lq, ri % Lq (exact for ri < 64)
+        const bool take = !need_walk && r < W;
+        const int src = take ? tbl[r] : lane;
+        float q[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; a++) q[a] = __shfl(qp.p2[a].x, src, WAVE);
+        const float sb = __shfl(wb, src, WAVE); const int si = __shfl(wi, src, WAVE), sp = __shfl(wp, src, WAVE);
+        if (take) {
+#pragma unroll
+            for (int a = 0; a < DIM; a++) { qp.p2[a].x = q[a]; qp.p2[a].y = q[a]; }
+            wb = sb; wi = si; wp = sp; owner = src;
+            thr = fminf(wb * 1.00002f, FLT_MAX);
+            const int leaf = sp >> 3, skip = (leaf >> (2 * (Lq - L - 1))) & 3;          // the child of my node that lies on the path: the next level's lane has it
+            st.L = L; st.idx = leaf >> (2 * (Lq - L)); st.alive = true;
+            f2 l01, l23;
+            quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * L)) - 1u)) + (unsigned int)st.idx, qp, l01, l23);
+            const float inf = __uint_as_float(NONE);
+            l01.x = skip == 0 ? inf : l01.x; l01.y = skip == 1 ? inf : l01.y; l23.x = skip == 2 ? inf : l23.x; l23.y = skip == 3 ? inf : l23.y;
+            descend(l01, l23);
+        }
+        if (need_walk) { st.L = Lq; st.idx = wp >> 3; }                   // the walker itself: straight to the seed's leaf
+    }
     for (;;) {
         if (!st.alive && owner >= 0) {
             // this lane's (part of the) search is over: fold it into the owner's record
@@ -805,17 +856,7 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
         while (st.alive && st.L < Lq) {
             f2 l01, l23;
             quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * st.L)) - 1u)) + (unsigned int)st.idx, qp, l01, l23);
-            const float m = fminf(fminf(l01.x, l01.y), fminf(l23.x, l23.y));
-            const bool s0 = !(l01.x > thr), s1 = !(l01.y > thr), s2 = !(l23.x > thr), s3 = !(l23.y > thr);
-            mlb = min(min(mlb, min(s0 ? NONE : __float_as_uint(l01.x), s1 ? NONE : __float_as_uint(l01.y))), min(s2 ? NONE : __float_as_uint(l23.x), s3 ? NONE : __float_as_uint(l23.y)));
-            if (!(m > thr)) {
-                const bool b0 = l01.x == m, b1 = l01.y == m, bb2 = l23.x == m;
-                int c = 3; c = bb2 ? 2 : c; c = b1 ? 1 : c; c = b0 ? 0 : c;
-                const unsigned int pend = ((s0 ? 1u : 0u) | (s1 ? 2u : 0u) | (s2 ? 4u : 0u) | (s3 ? 8u : 0u)) & ~(1u << c);
-                st.pending |= (MaskT)pend << (4 * st.L);
-                st.idx = (st.idx << 2) | c; st.L++;
-            } else st.alive = false;
-            quad_pop_bits(st);
+            descend(l01, l23);
             // Back to the hand-over as soon as it has something to do: while every idle lane found work last time (lanes are what is
             // scarce) when a lane runs out of work; otherwise (lanes idle, parked subtrees scarce) when a lane parks one.  Measured against
             // handing over only between leaves: iteration 0 0.142 -> 0.126 ms, iterations 1-9 0.065 -> 0.061, 10-16 0.033 -> 0.028.

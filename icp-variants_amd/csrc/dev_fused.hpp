@@ -33,13 +33,43 @@ struct P2pGen {                                           // values 0..21 = sum 
 // query, a stable 8-class rank in the epilogue): iterations 1-9 0.084 vs 0.079 ms -- the prediction is not worth the extra dependent
 // load in front of everything and the gathers.  What did pay was making k_reduce_solve itself cheaper (one load
 // round, fence-free hand-over): see dev_solve.hpp.
+#ifndef ICP_DEBUG_CUT
+#define ICP_DEBUG_CUT 0          // 1: development build, kp.nseg = 100 + c ends ONE chosen launch early at cut point c (its results are garbage; its duration is the point)
+#endif
+#if ICP_DEBUG_CUT
+#define ICP_CUT(c) do { if (kp.nseg == 100 + (c)) return; } while (0)
+#else
+#define ICP_CUT(c)
+#endif
+#ifndef ICP_DEBUG_TIMES
+#define ICP_DEBUG_TIMES 0        // 1 (with ICP_DEBUG_STEPS=1 for the buffer): lane 0 of every wave leaves 100 MHz timestamps of its phases in dbg_steps[8 * wave ..]
+#endif
+#if ICP_DEBUG_TIMES
+#define ICP_STAMP(j) do { if (kp.dbg_steps && lane == 0) kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + (j)] = (int)(unsigned int)wall_clock64(); } while (0)
+#else
+#define ICP_STAMP(j)
+#endif
+#ifndef ICP_KERNARG_UPFRONT
+#define ICP_KERNARG_UPFRONT 1
+#endif
 template <int DIM, bool WIDE>      // WIDE: trees deeper than 8 levels of 4-wide nodes (> 524 288 targets) keep 64 pending bits per lane
 __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {
     extern __shared__ uint2 bvh_lbq[];                    // [ICP_SHARE_ROWS][BVH_THREADS]: the shared walk's records; reused by the reduction
+#if ICP_KERNARG_UPFRONT
+    // The ~480 bytes of arguments are 8 cache lines; the compiler fetches each field where it is first used, behind branches, i.e. in
+    // half a dozen scalar-load-then-wait rounds spread over the front end -- and at the start of a launch every one of them misses.
+    // Naming the fields of the all-lanes path here makes them ONE batch of scalar loads and one wait.
+    asm volatile("" :: "s"(kp.sx), "s"(kp.sy), "s"(kp.sz), "s"(kp.sel), "s"(kp.n), "s"(kp.ps), "s"(kp.max_dist), "s"(kp.nn_raw), "s"(kp.use_prev),
+                 "s"(kp.qstate), "s"(kp.incremental), "s"(kp.qstate2), "s"(kp.d2_out), "s"(qorder), "s"(bv.recs), "s"(bv.n_valid), "s"(bv.Lq),
+                 "s"(pp.snx), "s"(pp.sny), "s"(pp.snz), "s"(pp.sel), "s"(pp.matches), "s"(pp.metric), "s"(pp.weighting), "s"(pp.rejection),
+                 "s"(pp.max_dist), "s"(pp.cos_reject), "s"(pp.partials), "s"(gridDim.x));
+#endif
     constexpr int NW = BVH_THREADS / WAVE;
+    ICP_CUT(1);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int t0 = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS;
     const int t = t0 + tid;
+    ICP_STAMP(0);
     const int k = (t < kp.n) ? (qorder ? qorder[t] : t) : -1;
     bool valid = false;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, wt = 0.f;
@@ -95,6 +125,13 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
             }
         }
     }
+    ICP_STAMP(1);
+#if ICP_DEBUG_TIMES
+    if (kp.dbg_steps) { const int nw_ = __popcll(__ballot(need_walk)), nl_ = __popcll(__ballot(leaf_only)); if (lane == 0) { kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + 6] = nw_; kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + 7] = nl_; } }
+#endif
+#if ICP_DEBUG_CUT
+    if (kp.nseg == 102) { if (k >= 0 && best == 123.f && lb_others == 77.f) pp.partials[0] = rn0 + rn1 + rn2 + lb_outleaf; return; }
+#endif
     if (leaf_only) {
         f2 p2[DIM];
 #pragma unroll
@@ -108,7 +145,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
     // parked subtrees off the lanes still searching.  (Until round 2 a wave with <= 16 walkers searched them level-synchronously in lane
     // groups instead; the shared walk does that case as well, 0.0281 vs 0.0306 ms in iterations 10-16, and the kernel without the second
     // code path needs 68 instead of 80 VGPRs.)
-#if ICP_DEBUG_STEPS
+#if ICP_DEBUG_STEPS && !ICP_DEBUG_TIMES
     if (k >= 0 && kp.dbg_steps) kp.dbg_steps[k] = need_walk ? -1 : leaf_only ? -2 : 0;      // -1: walk (overwritten with its length); -2: second tier, one leaf
 #endif
 #if ICP_SHARE_WALKS
@@ -120,6 +157,10 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
     }
 #else
     if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lb_outleaf, bvh_lbq, tid, (ICP_DEBUG_STEPS && kp.dbg_steps) ? kp.dbg_steps + k : nullptr);
+#endif
+    ICP_STAMP(2);
+#if ICP_DEBUG_CUT
+    if (kp.nseg == 103) { if (k >= 0 && best == 123.f && lb_others == 77.f) pp.partials[0] = rn0 + rn1 + rn2 + lb_outleaf + ra.x + rb.x; return; }
 #endif
     if (k >= 0) {
         // A verified query keeps its stored anchor (position of the last full search) and bound: the triangle test stays valid
@@ -138,6 +179,10 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
             valid = post_eval<true>(pp, k, m, d0, d1, d2, n0, n1, n2, __float_as_uint(rb.w), s0, s1, s2, wt, rn0, rn1, rn2);
         }
     }
+    ICP_STAMP(3);
+#if ICP_DEBUG_CUT
+    if (kp.nseg == 104) { if (valid && s0 == 123.f && wt == 77.f) pp.partials[0] = s1 + s2 + d0 + d1 + d2 + n0 + n1 + n2; return; }
+#endif
     __syncthreads();                                      // the traversal stacks are dead: reuse LDS for the reduction
     // ---- epilogue: the block's sums.  Every lane has at most one pair; its <= 27 contributions are folded over the wave with
     // the transposing reduction (wave_transpose_reduce_from: permlane swaps + DPP, no LDS traffic), the two wave totals meet in
@@ -153,6 +198,10 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
         const P2pGen g{{s0, s1, s2}, {d0, d1, d2}, (double)wt, valid};
         tot = wave_transpose_reduce_gen<6, 0>(g, lane);
     }
+    ICP_STAMP(4);
+#if ICP_DEBUG_CUT
+    if (kp.nseg == 105) { if (tot == 123.0) pp.partials[0] = tot; return; }
+#endif
     {
         const unsigned long long vm = __ballot(valid);    // the count is an integer: one ballot per wave
         const int v = wave_value_of_lane(lane);
@@ -173,4 +222,5 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
         }
         pp.partials[(size_t)tid * nb + lb] = out;
     }
+    ICP_STAMP(5);
 }

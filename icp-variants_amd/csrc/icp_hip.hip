@@ -90,6 +90,9 @@ struct icp_ctx {
     DevBuf sel_lists, sel_counts, sel_blocks;            // RANDOM_SAMPLING: per-iteration index lists, their sizes, scan scratch
     DevBuf qstate, qstate2;                              // incremental k-NN: per-query anchor + bound on the other targets; bound on the targets outside the neighbour's leaf
     DevBuf dbg_steps;                    // development builds only (ICP_DEBUG_STEPS)
+#if ICP_DEBUG_CUT
+    int dbg_iter = -1;             // development build: the launch of this iteration is cut short (ICP_HIP_DBG_CUT / ICP_HIP_DBG_CUT_ITER) to time its phases
+#endif
     DevBuf ps, matches, d2, best64, nn_raw, partials, totals, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
     Cloud conv_src, conv_ref; int conv_n = 0;
     float cos_reject = 0.5f;
@@ -432,6 +435,9 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
         PostParams pp = make_post_params(c, *fuse, kp.sel, n);
         pp.matches = nullptr;                                                     // the loop never reads the records of a fused iteration
         KnnParams kf = kp; kf.d2_out = nullptr; kf.out = nullptr;                 // ... nor the distances
+#if ICP_DEBUG_CUT
+        { const char* e = getenv("ICP_HIP_DBG_CUT"); const char* f = getenv("ICP_HIP_DBG_CUT_ITER"); kf.nseg = (e && f && atoi(f) == c->dbg_iter) ? 100 + atoi(e) : 1; }
+#endif
         const size_t red_bytes = (size_t)(BVH_THREADS / WAVE) * 33 * 8;           // the reduction reuses the (dead) traversal stacks
         const size_t lds = stack_bytes > red_bytes ? stack_bytes : red_bytes;
         if (b.Lq <= 8) hipLaunchKernelGGL((k_knn_bvh_post<DIM, false>), dim3(nb), dim3(BVH_THREADS), lds, c->stream, kf, bv, order, pp);
@@ -930,6 +936,9 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
             const bool seed = i > 0 && factors[i] == factors[i - 1] && ns[i - 1] > 0 && p.selection == 0;
             QuerySet q{clouds[i], sels[i], ns[i], 0, p.color_icp != 0 && p.matching == ICP_MATCH_KNN, seed, orders[i]};
             int fused = 0;
+#if ICP_DEBUG_CUT
+            c->dbg_iter = i;
+#endif
             if ((rc = launch_match(c, q, c->fuse_post ? &fused : nullptr))) return rc;
             if (ev) HIPCK(c, hipEventRecord(E(i, 1), c->stream));
             // fused epilogue: there is no separate post stage to bracket

@@ -1,0 +1,36 @@
+"""Dev tool (needs a build with ICP_DEBUG_STEPS=1 ICP_DEBUG_TIMES=1: ICP_HIP_LIB=.../libicp_hip_times.so): where the waves of ONE launch of the
+fused matcher spend their time.  Lane 0 of every wave stamps the 100 MHz clock at the start, after the front end (loads + verify test), after the
+walks, after weighting/rejection, after the wave reduction and at the end.  usage: ICP_HIP_LIB=... python tools/dev_wave_times.py [iterations ...]"""
+import sys, os, ctypes as C
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "icp-variants_amd", "python"))
+import numpy as np
+from icp_amd import binding, synth
+p = synth.eth_like_pair(0)
+n = len(p["src_pts"])
+c = binding.Context(0)
+c.params.max_distance = 10.0; c.params.metric = 1; c.params.knn_backend = 1
+c.set_stage_timing(0)
+c.push_params(); c.set_target(p["tgt_pts"], p["tgt_nrm"]); c.set_source(p["src_pts"], p["src_nrm"])
+nw = ((n + 127) // 128) * 2
+for iters in [int(a) for a in sys.argv[1:]] or [1, 3, 6, 12, 45]:
+    c.params.n_iterations = iters; c.push_params()
+    c.run(np.eye(4))
+    buf = np.zeros(n, np.int32)
+    assert c.lib.icp_debug_steps(c.h, buf.ctypes.data_as(C.c_void_p), C.c_int32(n)) == 0
+    w = buf[: nw * 8].reshape(nw, 8)
+    t = w[:, :6].astype(np.uint32).astype(np.int64)
+    t0 = t[:, 0].min()
+    rel = (t - t0) * 0.01                                     # us since the first wave started
+    walkers = w[:, 6]; leaf_only = w[:, 7]
+    names = ["start", "front", "walks", "post", "reduce", "end"]
+    print("iteration %d: %d waves, %d with walkers (%d walking queries), %d leaf-only queries; launch spans %.2f us from the first stamp"
+          % (iters - 1, nw, (walkers > 0).sum(), walkers.sum(), leaf_only.sum(), rel[:, 5].max()))
+    for label, m in (("all waves", np.ones(nw, bool)), ("waves without walkers", walkers == 0), ("waves with walkers", walkers > 0)):
+        if not m.any(): continue
+        r = rel[m]
+        print("  %-22s" % label + "  ".join("%s: mean %.2f p99 %.2f max %.2f" % (names[j], r[:, j].mean(), np.percentile(r[:, j], 99), r[:, j].max()) for j in range(6)))
+        d = np.diff(r, axis=1)
+        print("  %-22s" % "  (phase lengths)" + "  ".join("%s: mean %.2f max %.2f" % (names[j + 1], d[:, j].mean(), d[:, j].max()) for j in range(5)))
+    last = np.argsort(rel[:, 5])[-5:]
+    for i in last: print("   late wave %5d: walkers %2d  stamps %s" % (i, walkers[i], np.round(rel[i], 2)))
