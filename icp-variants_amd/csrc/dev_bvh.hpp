@@ -23,6 +23,13 @@
 #ifndef ICP_SEED_DESCENT
 #define ICP_SEED_DESCENT 1
 #endif
+#ifndef ICP_PRUNE_SLACK
+// A box is skipped when its (squared) bound exceeds best * ICP_PRUNE_SLACK.  Anything above 1 + a few ulp is exact.  But a box skipped with a
+// bound barely above the neighbour's distance leaves the query a bound on "everything else" with no margin, and it can then never be
+// verified without a search: 1.001 (0.05 % in distance, far more than a query moves per iteration once ICP has converged) costs a
+// handful of extra box visits and retires those queries.  (Until round 2: 1.00002.)
+#define ICP_PRUNE_SLACK 1.001f
+#endif
 #ifndef ICP_PREFETCH_PATH
 #define ICP_PREFETCH_PATH 1
 #endif
@@ -439,13 +446,21 @@ __device__ __forceinline__ f2 pair_lb(const BvhNodeT<DIM>* __restrict__ nd, cons
     return acc;
 }
 
-// Evaluate the 8 points of a leaf against the lane's query; exact lexicographic (d2, lowest index) update.
-// best2 follows the smallest distance among all evaluated points OTHER than the current winner (see k_knn_bvh); out2 the smallest
-// distance among the evaluated points of every leaf other than the WINNER'S LEAF (second verification tier, knn_leaf_bound): a leaf
-// that does not take the win contributes its minimum, a leaf that takes it sends the dethroned winner's distance -- the minimum of
-// the leaf the winner leaves -- there.  (A leaf visited while it already holds the winner contributes nothing.)
+// What a search remembers about the points that did NOT win, for next iteration's verify tests: b2 = the smallest distance among them
+// and l2 = the leaf that point lives in (the runner-up's leaf; it can be the winner's own leaf), b3 = a lower bound on the non-winners
+// outside leaf l2.  An entry is (distance, leaf); entries of leaf l2 other than the runner-up itself may or may not reach b3 -- either
+// way b3 stays a valid (if smaller) bound.
+__device__ __forceinline__ void others_insert(float x, int xl, float& b2, int& l2, float& b3) {
+    const bool better = x < b2, same = xl == l2;
+    b3 = same ? b3 : fminf(b3, better ? b2 : x);
+    l2 = better ? xl : l2; b2 = better ? x : b2;
+}
+
+// Evaluate the 8 points of a leaf against the lane's query; exact lexicographic (d2, lowest index) update.  The leaf's non-winners
+// enter (b2, l2, b3) as ONE entry (their minimum); when the win moves here from another leaf, the dethroned winner -- the minimum of
+// the leaf it lives in, as far as this search has seen it -- enters under that leaf.
 template <int DIM>
-__device__ __forceinline__ void leaf_eval(const BvhLeafT<DIM>* __restrict__ lf, int leaf, const f2* p2, float& best, int& bi, int& bpos, float& best2, float& out2) {
+__device__ __forceinline__ void leaf_eval(const BvhLeafT<DIM>* __restrict__ lf, int leaf, const f2* p2, float& best, int& bi, int& bpos, float& b2, int& l2, float& b3) {
     const int prev_leaf = bpos >> 3; const float prev_best = best;
     float dd[BVH_LEAF];
     float m = FLT_MAX;
@@ -463,16 +478,20 @@ __device__ __forceinline__ void leaf_eval(const BvhLeafT<DIM>* __restrict__ lf, 
         m = fminf(fminf(m, d.x), d.y);
     }
     if (m <= best) {                     // something in this leaf ties or beats the running best (or IS the running best)
+        float mo = FLT_MAX;              // smallest distance among this leaf's points that do not end up as the winner
+        bool here = prev_leaf == leaf;   // the running winner lives in this leaf
 #pragma unroll
         for (int t = 0; t < BVH_LEAF; t++) {
             const int j = lf->idx[t];
             const bool take = (dd[t] < best) | ((dd[t] == best) & (j < bi));     // first minimum = lowest original index
-            const float other = take ? best : ((j != bi) ? dd[t] : FLT_MAX);      // the dethroned winner, or a non-winning point
-            best2 = fminf(best2, other);
+            const float other = take ? (here ? best : FLT_MAX) : ((j != bi) ? dd[t] : FLT_MAX);      // a winner of this leaf dethroned by a later one, or a plain non-winner
+            mo = fminf(mo, other);
+            here = here | take;
             best = take ? dd[t] : best; bi = take ? j : bi; bpos = take ? leaf * BVH_LEAF + t : bpos;
         }
-    } else best2 = fminf(best2, m);      // nobody here can win: all 8 are "others"
-    if (leaf != prev_leaf) out2 = fminf(out2, (bpos >> 3) == leaf ? prev_best : m);
+        others_insert(mo, leaf, b2, l2, b3);
+        if (prev_leaf != leaf && (bpos >> 3) == leaf) others_insert(prev_best, prev_leaf, b2, l2, b3);      // the win moved here (an unseeded start enters (FLT_MAX, -1): nothing)
+    } else others_insert(m, leaf, b2, l2, b3);      // nobody here can win: all 8 are "others"
 }
 
 // Temporal seeding: ICP moves the queries a little per iteration, so the previous iteration's neighbour j0 is a
@@ -599,11 +618,11 @@ __device__ int g_dbg_nodes_dummy;
 #endif
 template <int DIM, class MaskT>
 __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<DIM>& qp, QuadStateT<MaskT>& st,
-                                         float& best, int& bi, int& bpos, float& best2, float& out2, float& minlb, int& dbg_nodes, int& dbg_leaves) {
+                                         float& best, int& bi, int& bpos, float& b2, int& l2, float& b3, float& minlb, int& dbg_nodes, int& dbg_leaves) {
     const int Lq = bv.Lq;
     // A box is skipped when its lower bound exceeds thr = best * (1 + 2e-5) (clamped so that the +inf bound of an empty box is
     // always skipped): that implies bound > best with margin, one multiply per change of `best` instead of one per box test.
-    float thr = fminf(best * 1.00002f, FLT_MAX);
+    float thr = fminf(best * ICP_PRUNE_SLACK, FLT_MAX);
     // smallest skipped bound, kept as its bit pattern: bounds are >= +0, so unsigned order is value order and the integer minimum
     // needs none of the NaN canonicalisation a float minimum of selected values drags in
     unsigned int mlb = __float_as_uint(minlb);
@@ -619,8 +638,8 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<
             if (!(m > thr)) {
                 // nearest child first (selects, not branches).  Measured: taking the survivors in index order instead saves 5 instructions
                 // per node and costs 0.080 -> 0.096 ms in iterations 1-9 (0.17 -> 0.80 ms unseeded): the order is worth its price.
-                const bool b0 = l01.x == m, b1 = l01.y == m, b2 = l23.x == m;
-                int c = 3; c = b2 ? 2 : c; c = b1 ? 1 : c; c = b0 ? 0 : c;
+                const bool c0 = l01.x == m, c1 = l01.y == m, c2 = l23.x == m;
+                int c = 3; c = c2 ? 2 : c; c = c1 ? 1 : c; c = c0 ? 0 : c;
                 const unsigned int pend = ((s0 ? 1u : 0u) | (s1 ? 2u : 0u) | (s2 ? 4u : 0u) | (s3 ? 8u : 0u)) & ~(1u << c);
                 st.pending |= (MaskT)pend << (4 * st.L);
                 st.idx = (st.idx << 2) | c; st.L++;
@@ -629,8 +648,8 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<
         }
         if (st.alive) {
             ICP_COUNT_STEP(dbg_leaves);
-            leaf_eval<DIM>(bv.leaves + st.idx, st.idx, qp.p2, best, bi, bpos, best2, out2);
-            thr = fminf(best * 1.00002f, FLT_MAX);
+            leaf_eval<DIM>(bv.leaves + st.idx, st.idx, qp.p2, best, bi, bpos, b2, l2, b3);
+            thr = fminf(best * ICP_PRUNE_SLACK, FLT_MAX);
             st.alive = false;
             quad_pop_bits(st);
         }
@@ -684,9 +703,9 @@ __device__ __forceinline__ bool knn_try_verify(const KnnParams& kp, const BvhVie
 }
 
 template <int DIM>
-__device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, const float* p, float best, int bpos, float lb_others, float lb_outleaf) {
+__device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, const float* p, float best, int bpos, float lb_others, float lb3, int l2) {
     if (kp.qstate) { float4 s; s.x = p[0]; s.y = p[1]; s.z = p[2]; s.w = lb_others; kp.qstate[k] = s; }
-    if (kp.qstate2) kp.qstate2[k] = lb_outleaf;
+    if (kp.qstate2) { float2 t; t.x = lb3; t.y = __int_as_float(l2); kp.qstate2[k] = t; }
     if (kp.nn_raw) kp.nn_raw[k] = bpos;
     if (kp.d2_out) kp.d2_out[k] = best;
 }
@@ -711,7 +730,7 @@ __device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, cons
 // Rows of the wave's LDS slots: 0 key, 1 (others, skipped bound), 2 (out-of-leaf, position), 3-5 and 7-9 the lanes' own results,
 // query and normal parked meanwhile (so that a helper needs no registers of its own for them), 6 the donors' lane numbers.
 template <int DIM, int NT, class MaskT>
-__device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* p, float* keep3, bool need_walk, float& best, int& bi, int& bpos, float& lb_others, float& lb_outleaf,
+__device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* p, float* keep3, bool need_walk, float& best, int& bi, int& bpos, float& lb_others, float& lb3, int& l2o,
                                                 uint2* __restrict__ lbq, int tid) {
     const int lane = tid & 63, Lq = bv.Lq;
     uint2* R = lbq + (tid & ~63);
@@ -719,13 +738,14 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
     unsigned long long* keys = (unsigned long long*)R;                    // keys[l]
     R[3 * NT + lane] = make_uint2(__float_as_uint(best), (unsigned int)bi);
     R[4 * NT + lane] = make_uint2((unsigned int)bpos, __float_as_uint(lb_others));
-    R[5 * NT + lane] = make_uint2(__float_as_uint(lb_outleaf), __float_as_uint(p[0]));
+    R[5 * NT + lane] = make_uint2(__float_as_uint(lb3), __float_as_uint(p[0]));
     R[7 * NT + lane] = make_uint2(__float_as_uint(p[1]), __float_as_uint(p[2]));
     R[8 * NT + lane] = make_uint2(__float_as_uint(keep3[0]), __float_as_uint(keep3[1]));
-    R[9 * NT + lane] = make_uint2(__float_as_uint(keep3[2]), 0u);
+    R[9 * NT + lane] = make_uint2(__float_as_uint(keep3[2]), (unsigned int)l2o);
     keys[lane] = ~0ull;
-    R[1 * NT + lane] = make_uint2(FMAXB, FMAXB);
-    R[2 * NT + lane] = make_uint2(FMAXB, 0xFFFFFFFFu);
+    keys[NT + lane] = ~0ull;                                               // row 1: the runner-up entry (distance, leaf)
+    R[2 * NT + lane] = make_uint2(FMAXB, 0xFFFFFFFFu);                     // row 2: (bound on the rest, position of the winner)
+    ((unsigned int*)(R + 6 * NT))[WAVE + lane] = FMAXB;                    // row 6, second half: smallest skipped box bound
     QueryPt<DIM> qp;
     make_query<DIM>(bv, p, qp);
     float wb = best; int wi = bi, wp = bpos;
@@ -740,8 +760,8 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
                 const int c = (l01.x == m) ? 0 : (l01.y == m) ? 1 : (l23.x == m) ? 2 : 3;
                 idx = (idx << 2) | c;
             }
-            float unused = FLT_MAX, unused2 = FLT_MAX;
-            leaf_eval<DIM>(bv.leaves + idx, idx, qp.p2, wb, wi, wp, unused, unused2);
+            float u2 = FLT_MAX, u3 = FLT_MAX; int ul = -1;
+            leaf_eval<DIM>(bv.leaves + idx, idx, qp.p2, wb, wi, wp, u2, ul, u3);
         }
     }
     // Few walkers, all with a seed: the seed's root-to-leaf path is known, so its Lq nodes need not be visited one after the other.
@@ -752,19 +772,19 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
     const int W = __popcll(wm);
     const bool spread = ICP_SHARE_SPREAD && Lq > 0 && W * (Lq + 1) <= WAVE && wm == __ballot(need_walk && wp >= 0);
     if (ICP_PREFETCH_PATH && !spread && need_walk && wp >= 0) touched = quad_prefetch_path<DIM>(bv, wp >> 3);
-    float b2 = FLT_MAX, o2 = FLT_MAX;
+    float b2 = FLT_MAX, b3 = FLT_MAX; int l2 = -1;
     unsigned int mlb = FMAXB;
     int owner = need_walk ? lane : -1;                                    // whose query this lane is searching for; -1: idle
     QuadStateT<MaskT> st; st.L = 0; st.idx = 0; st.pending = 0; st.alive = need_walk;
-    float thr = fminf(wb * 1.00002f, FLT_MAX);
+    float thr = fminf(wb * ICP_PRUNE_SLACK, FLT_MAX);
     // one node step on the child bounds of node (st.L, st.idx): nearest surviving child next, the other survivors parked
     auto descend = [&](const f2& l01, const f2& l23) {
         const float m = fminf(fminf(l01.x, l01.y), fminf(l23.x, l23.y));
         const bool s0 = !(l01.x > thr), s1 = !(l01.y > thr), s2 = !(l23.x > thr), s3 = !(l23.y > thr);
         mlb = min(min(mlb, min(s0 ? NONE : __float_as_uint(l01.x), s1 ? NONE : __float_as_uint(l01.y))), min(s2 ? NONE : __float_as_uint(l23.x), s3 ? NONE : __float_as_uint(l23.y)));
         if (!(m > thr)) {
-            const bool b0 = l01.x == m, b1 = l01.y == m, bb2 = l23.x == m;
-            int c = 3; c = bb2 ? 2 : c; c = b1 ? 1 : c; c = b0 ? 0 : c;
+            const bool c0 = l01.x == m, c1 = l01.y == m, c2 = l23.x == m;
+            int c = 3; c = c2 ? 2 : c; c = c1 ? 1 : c; c = c0 ? 0 : c;
             const unsigned int pend = ((s0 ? 1u : 0u) | (s1 ? 2u : 0u) | (s2 ? 4u : 0u) | (s3 ? 8u : 0u)) & ~(1u << c);
             st.pending |= (MaskT)pend << (4 * st.L);
             st.idx = (st.idx << 2) | c; st.L++;
@@ -787,7 +807,7 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
 #pragma unroll
             for (int a = 0; a < DIM; a++) { qp.p2[a].x = q[a]; qp.p2[a].y = q[a]; }
             wb = sb; wi = si; wp = sp; owner = src;
-            thr = fminf(wb * 1.00002f, FLT_MAX);
+            thr = fminf(wb * ICP_PRUNE_SLACK, FLT_MAX);
             const int leaf = sp >> 3, skip = (leaf >> (2 * (Lq - L - 1))) & 3;          // the child of my node that lies on the path: the next level's lane has it
             st.L = L; st.idx = leaf >> (2 * (Lq - L)); st.alive = true;
             f2 l01, l23;
@@ -800,17 +820,30 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
     }
     for (;;) {
         if (!st.alive && owner >= 0) {
-            // this lane's (part of the) search is over: fold it into the owner's record
+            // this lane's (part of the) search is over: fold it into the owner's record.  Winner: 64-bit minimum of (distance, index).
+            // Runner-up entry (distance, leaf): 64-bit minimum as well; whatever loses there -- and is not in the same leaf as what beat
+            // it: such a point is bounded by that entry for as long as it stands, and by its distance in the rest once it falls -- goes to
+            // the bound on the rest.  A winner of mine that loses is an entry of its own leaf; a winner I dethrone has no leaf on record:
+            // straight to the rest (smaller bound than needed, for this one iteration).
             const unsigned long long mykey = ((unsigned long long)__float_as_uint(wb) << 32) | (unsigned int)wi;
             const unsigned long long old = __hip_atomic_fetch_min(keys + owner, mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            unsigned int* om = (unsigned int*)(R + 1 * NT + owner);       // {others, skipped}
-            unsigned int* op = (unsigned int*)(R + 2 * NT + owner);       // {out of leaf, position}
-            // whoever of the two candidates is not the minimum is an "other" point (the record's initial key stands for none)
-            const unsigned int loser = old == mykey ? FMAXB : old < mykey ? __float_as_uint(wb) : old == ~0ull ? FMAXB : (unsigned int)(old >> 32);
-            __hip_atomic_fetch_min(om, min(loser, __float_as_uint(b2)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_min(om + 1, mlb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_min(op, owner == lane ? __float_as_uint(o2) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (keys[owner] == mykey) op[1] = (unsigned int)wp;
+            unsigned int* bp = (unsigned int*)(R + 2 * NT + owner);       // {rest, position}
+            unsigned int rest = __float_as_uint(b3);
+            unsigned long long e = ((unsigned long long)__float_as_uint(b2) << 32) | (unsigned int)l2;
+            if (old < mykey) {
+                const unsigned long long w = ((unsigned long long)__float_as_uint(wb) << 32) | (unsigned int)(wp >> 3);
+                const unsigned long long lo = w < e ? w : e, hi = w < e ? e : w;
+                if ((unsigned int)lo != (unsigned int)hi) rest = min(rest, (unsigned int)(hi >> 32));
+                e = lo;
+            } else if (old > mykey && old != ~0ull) rest = min(rest, (unsigned int)(old >> 32));
+            {
+                const unsigned long long o2 = __hip_atomic_fetch_min(keys + NT + owner, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned long long lo = o2 < e ? o2 : e, hi = o2 < e ? e : o2;
+                if (hi != ~0ull && (unsigned int)lo != (unsigned int)hi) rest = min(rest, (unsigned int)(hi >> 32));
+            }
+            __hip_atomic_fetch_min(bp, rest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_min((unsigned int*)(R + 6 * NT) + WAVE + owner, mlb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (keys[owner] == mykey) bp[1] = (unsigned int)wp;
             owner = -1;
         }
         if (!__any(st.alive)) break;
@@ -847,8 +880,8 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
 #pragma unroll
                     for (int a = 0; a < DIM; a++) { qp.p2[a].x = q[a]; qp.p2[a].y = q[a]; }
                     wb = sb; wi = si; wp = sp; owner = so;
-                    b2 = FLT_MAX; o2 = FLT_MAX; mlb = FMAXB;
-                    thr = fminf(wb * 1.00002f, FLT_MAX);
+                    b2 = FLT_MAX; b3 = FLT_MAX; l2 = -1; mlb = FMAXB;
+                    thr = fminf(wb * ICP_PRUNE_SLACK, FLT_MAX);
                     st.L = sL; st.idx = sI; st.pending = 0; st.alive = true;
                 }
             }
@@ -863,8 +896,8 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
             if (served ? __any(!st.alive) : __any(st.pending != 0)) break;
         }
         if (st.alive && st.L == Lq) {                                      // (a lane that left the loop above early is still at a node)
-            leaf_eval<DIM>(bv.leaves + st.idx, st.idx, qp.p2, wb, wi, wp, b2, o2);
-            thr = fminf(wb * 1.00002f, FLT_MAX);
+            leaf_eval<DIM>(bv.leaves + st.idx, st.idx, qp.p2, wb, wi, wp, b2, l2, b3);
+            thr = fminf(wb * ICP_PRUNE_SLACK, FLT_MAX);
             st.alive = false;
             quad_pop_bits(st);
         }
@@ -876,15 +909,19 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
         keep3[0] = __uint_as_float(e.x); keep3[1] = __uint_as_float(e.y); keep3[2] = __uint_as_float(f.x);
     }
     if (need_walk) {
-        const unsigned long long key = keys[lane];
-        const uint2 a = R[1 * NT + lane], b = R[2 * NT + lane];
+        const unsigned long long key = keys[lane], key2 = keys[NT + lane];
+        const uint2 b = R[2 * NT + lane];
         best = __uint_as_float((unsigned int)(key >> 32)); bi = (int)(unsigned int)key; bpos = (int)b.y;
-        const float sk = __uint_as_float(a.y);
-        lb_others = sqrtf(fminf(__uint_as_float(a.x), sk)) * 0.999999f;
-        lb_outleaf = sqrtf(fminf(__uint_as_float(b.x), sk)) * 0.999999f;
+        const float sk = __uint_as_float(((const unsigned int*)(R + 6 * NT))[WAVE + lane]);
+        const float rest = fminf(__uint_as_float(b.x), sk);
+        // (a winner dethroned during the merge went straight to the rest: it can be nearer than the runner-up entry.  No entry at all: the
+        //  initial key reads as a NaN distance and fminf returns the other operand)
+        lb_others = sqrtf(fminf(__uint_as_float((unsigned int)(key2 >> 32)), rest)) * 0.999999f;
+        lb3 = sqrtf(rest) * 0.999999f;
+        l2o = key2 == ~0ull ? -1 : (int)(unsigned int)key2;
     } else {
         const uint2 a = R[3 * NT + lane], b = R[4 * NT + lane], c = R[5 * NT + lane];
-        best = __uint_as_float(a.x); bi = (int)a.y; bpos = (int)b.x; lb_others = __uint_as_float(b.y); lb_outleaf = __uint_as_float(c.x);
+        best = __uint_as_float(a.x); bi = (int)a.y; bpos = (int)b.x; lb_others = __uint_as_float(b.y); lb3 = __uint_as_float(c.x); l2o = (int)R[9 * NT + lane].y;
     }
 }
 
@@ -903,11 +940,11 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // The tree walk proper for query p, starting from the seed (best, bi, bpos); returns the lower bound on the distance to every
 // target other than the winner.  NT = threads of the block (layout of the LDS stacks).
 template <int DIM, int NT>
-__device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* p, float& best, int& bi, int& bpos, float& lb_outleaf, uint2* __restrict__ lbq, int tid, int* dbg_out = nullptr) {
+__device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* p, float& best, int& bi, int& bpos, float& lb3, int& l2, uint2* __restrict__ lbq, int tid, int* dbg_out = nullptr) {
     int dbg_nodes = 0, dbg_leaves = 0;
     QueryPt<DIM> qp;
     make_query<DIM>(bv, p, qp);
-    float best2 = FLT_MAX, out2 = FLT_MAX, minlb = FLT_MAX;
+    float b2 = FLT_MAX, b3 = FLT_MAX, minlb = FLT_MAX; l2 = -1;
     unsigned int touched = 0u;
     if (ICP_SEED_DESCENT && bpos < 0 && bv.Lq > 0) {
         // No candidate yet (first iteration): one greedy root-to-leaf descent -- nearest child at every level, nothing parked --
@@ -921,23 +958,23 @@ __device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* 
             const int c = (l01.x == m) ? 0 : (l01.y == m) ? 1 : (l23.x == m) ? 2 : 3;
             idx = (idx << 2) | c;
         }
-        float unused = FLT_MAX, unused2 = FLT_MAX;
-        leaf_eval<DIM>(bv.leaves + idx, idx, qp.p2, best, bi, bpos, unused, unused2);      // (the walk re-evaluates this leaf: the bound bookkeeping stays in one place)
+        float u2 = FLT_MAX, u3 = FLT_MAX; int ul = -1;
+        leaf_eval<DIM>(bv.leaves + idx, idx, qp.p2, best, bi, bpos, u2, ul, u3);      // (the walk re-evaluates this leaf: the bound bookkeeping stays in one place)
     }
     if (ICP_PREFETCH_PATH && bpos >= 0) touched = quad_prefetch_path<DIM>(bv, bpos >> 3);
     if (bv.Lq <= 8) {                                     // uniform: up to 8 levels (524 288 targets) the pending bits fit 32 bits
         QuadStateT<unsigned int> st; st.L = 0; st.idx = 0; st.pending = 0u; st.alive = true;
-        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, out2, minlb, dbg_nodes, dbg_leaves);
+        quad_run<DIM>(bv, qp, st, best, bi, bpos, b2, l2, b3, minlb, dbg_nodes, dbg_leaves);
     } else {
         QuadStateT<unsigned long long> st; st.L = 0; st.idx = 0; st.pending = 0ull; st.alive = true;
-        quad_run<DIM>(bv, qp, st, best, bi, bpos, best2, out2, minlb, dbg_nodes, dbg_leaves);
+        quad_run<DIM>(bv, qp, st, best, bi, bpos, b2, l2, b3, minlb, dbg_nodes, dbg_leaves);
     }
 #if ICP_DEBUG_STEPS
     if (dbg_out) *dbg_out = dbg_nodes | (dbg_leaves << 16);
 #endif
     asm volatile("" ::"v"(touched));
-    lb_outleaf = sqrtf(fminf(out2, minlb)) * 0.999999f;
-    return sqrtf(fminf(best2, minlb)) * 0.999999f;
+    lb3 = sqrtf(fminf(b3, minlb)) * 0.999999f;
+    return sqrtf(fminf(b2, minlb)) * 0.999999f;
 }
 
 // One query per lane (k < 0: none), the whole wave together: the lanes without a walk of their own help with the others'.
@@ -949,23 +986,23 @@ __device__ __forceinline__ void knn_bvh_query(const KnnParams& kp, const BvhView
     for (int q = 0; q < DIM; q++) p[q] = 0.f;
     if (k >= 0) knn_load_query<DIM>(kp, k, p);
     best = FLT_MAX; bi = -1; bpos = -1;
-    float lb_others = 0.f, lb_outleaf = 0.f;      // lower bounds on the (real) distance from p to every target except bi / outside bi's leaf
+    float lb_others = 0.f, lb3 = 0.f; int l2 = -1;  // lower bounds on the (real) distance from p to every target except bi / outside bi's leaf and leaf l2
     bool need_walk = false;
     if (k >= 0 && finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
-        // (a query verified here re-anchors; its leaf bound shrinks by the same step: lb_others is already L - delta)
-        if (knn_try_verify<DIM>(kp, bv, k, p, best, bi, bpos, lb_others)) lb_outleaf = lb_others;
+        // (a query verified here re-anchors: lb_others is already L - delta, and it bounds everything outside the neighbour's leaf too)
+        if (knn_try_verify<DIM>(kp, bv, k, p, best, bi, bpos, lb_others)) lb3 = lb_others;
         else need_walk = true;
     }
 #if ICP_SHARE_WALKS
     if (__any(need_walk)) {
         float none[3] = {0.f, 0.f, 0.f};
-        if (bv.Lq <= 8) knn_walk_shared<DIM, BVH_THREADS, unsigned int>(bv, p, none, need_walk, best, bi, bpos, lb_others, lb_outleaf, lbq, tid);
-        else knn_walk_shared<DIM, BVH_THREADS, unsigned long long>(bv, p, none, need_walk, best, bi, bpos, lb_others, lb_outleaf, lbq, tid);
+        if (bv.Lq <= 8) knn_walk_shared<DIM, BVH_THREADS, unsigned int>(bv, p, none, need_walk, best, bi, bpos, lb_others, lb3, l2, lbq, tid);
+        else knn_walk_shared<DIM, BVH_THREADS, unsigned long long>(bv, p, none, need_walk, best, bi, bpos, lb_others, lb3, l2, lbq, tid);
     }
 #else
-    if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lb_outleaf, lbq, tid);
+    if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lb3, l2, lbq, tid);
 #endif
-    if (k >= 0) knn_store_state<DIM>(kp, k, p, best, bpos, lb_others, lb_outleaf);
+    if (k >= 0) knn_store_state<DIM>(kp, k, p, best, bpos, lb_others, lb3, l2);
 }
 
 // Which query does this lane serve?  Position t of the (Morton-sorted) query order, in XCD-contiguous slices.

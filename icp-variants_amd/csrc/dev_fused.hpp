@@ -79,8 +79,11 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
     float rn0 = 0.f, rn1 = 0.f, rn2 = 0.f;
     float best = FLT_MAX, lb_others = 0.f; int bi = -1, bpos = -1, q0 = -1;
     float4 ra, rb; ra.x = 0.f; ra.y = 0.f; ra.z = 0.f; ra.w = 0.f; rb = ra;
+#if ICP_DEBUG_TIMES
+    float dbg_lbo = 0.f, dbg_lb3 = 0.f, dbg_delta = 0.f;
+#endif
     bool need_walk = false, verified = false, leaf_only = false;
-    float lb_outleaf = 0.f;                               // bound on every target outside the winner's leaf (second verification tier)
+    float lb3 = 0.f; int l2 = -1;                         // second verification tier: bound on every target outside the neighbour's leaf and the runner-up's leaf l2
     if (k >= 0) {
         // ---- front end.  Everything that depends only on the query index is requested in ONE batch (point, normal, previous
         // neighbour, search state), then the neighbour's record: two memory round trips before the verify test instead of
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
         const bool seeded = kp.use_prev != 0, inc = kp.incremental && seeded;
         q0 = seeded ? kp.nn_raw[k] : -1;
         float4 st; st.x = 0.f; st.y = 0.f; st.z = 0.f; st.w = 0.f;
-        float st2 = 0.f;
+        float2 st2; st2.x = 0.f; st2.y = __int_as_float(-1);
         if (inc) { st = kp.qstate[k]; if (kp.qstate2) st2 = kp.qstate2[k]; }
         xform_point(kp.ps->pose, r0, r1, r2, p[0], p[1], p[2]);
         if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
@@ -114,12 +117,17 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
                     const float ex = p[0] - st.x, ey = p[1] - st.y, ez = p[2] - st.z;
                     const float delta = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.000001f + 1e-30f;
                     const float lbn = (st.w - delta) * 0.999999f;
+#if ICP_DEBUG_TIMES
+                    dbg_lbo = st.w; dbg_lb3 = st2.x; dbg_delta = delta;
+#endif
                     if (sqrtf(best) * 1.000001f < lbn) { lb_others = lbn; need_walk = false; verified = true; }
                     else {
-                        // second tier: every target OUTSIDE the neighbour's leaf is still provably farther than the neighbour itself ->
-                        // the nearest neighbour is one of that leaf's 8 points: one leaf evaluation instead of a walk
-                        const float lb2 = (st2 - delta) * 0.999999f;
-                        if (sqrtf(best) * 1.000001f < lb2) { leaf_only = true; lb_outleaf = lb2; }
+                        // second tier: every target outside TWO leaves -- the neighbour's and the one the runner-up of the last search lives
+                        // in -- is still provably farther than the old neighbour itself -> the nearest neighbour is one of their 16 points: two
+                        // leaf evaluations instead of a walk.  This is what retires the queries that sit close to the bisector of two targets,
+                        // which the first tier can never verify and which would otherwise walk in every iteration.
+                        const float lb2 = (st2.x - delta) * 0.999999f;
+                        if (sqrtf(best) * 1.000001f < lb2) { leaf_only = true; lb3 = lb2; l2 = __float_as_int(st2.y); }
                     }
                 }
             }
@@ -127,18 +135,28 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
     }
     ICP_STAMP(1);
 #if ICP_DEBUG_TIMES
-    if (kp.dbg_steps) { const int nw_ = __popcll(__ballot(need_walk)), nl_ = __popcll(__ballot(leaf_only)); if (lane == 0) { kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + 6] = nw_; kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + 7] = nl_; } }
+    if (kp.dbg_steps && k >= 0 && (need_walk || leaf_only) && kp.use_prev) {      // who is it that still searches?  (slot by query index; the clock tells the launch)
+        int* r = kp.dbg_steps + 8 * (gridDim.x * NW) + 8 * (k & 4095);
+        r[0] = k; r[1] = __float_as_int(best); r[2] = __float_as_int(dbg_lbo); r[3] = __float_as_int(dbg_lb3); r[4] = __float_as_int(dbg_delta); r[5] = leaf_only ? l2 : -2; r[6] = q0; r[7] = (int)(unsigned int)wall_clock64();
+    }
+#endif
+#if ICP_DEBUG_TIMES
+    if (kp.dbg_steps) { const int nw_ = __popcll(__ballot(need_walk && !leaf_only)), nl_ = __popcll(__ballot(leaf_only)); if (lane == 0) { kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + 6] = nw_; kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + 7] = nl_; } }
 #endif
 #if ICP_DEBUG_CUT
-    if (kp.nseg == 102) { if (k >= 0 && best == 123.f && lb_others == 77.f) pp.partials[0] = rn0 + rn1 + rn2 + lb_outleaf; return; }
+    if (kp.nseg == 102) { if (k >= 0 && best == 123.f && lb_others == 77.f) pp.partials[0] = rn0 + rn1 + rn2 + lb3; return; }
 #endif
     if (leaf_only) {
         f2 p2[DIM];
 #pragma unroll
         for (int q = 0; q < DIM; q++) { p2[q].x = p[q]; p2[q].y = p[q]; }
-        float b2 = FLT_MAX, o2 = FLT_MAX;
-        leaf_eval<DIM>(bv.leaves + (q0 >> 3), q0 >> 3, p2, best, bi, bpos, b2, o2);      // exact argmin over the leaf, seeded with the old neighbour
-        lb_others = fminf(sqrtf(b2) * 0.999999f, lb_outleaf);                           // re-anchored here: second best of the leaf, or anything outside it
+        float b2 = FLT_MAX, b3 = FLT_MAX; int nl2 = -1;
+        const int lf = q0 >> 3;
+        leaf_eval<DIM>(bv.leaves + lf, lf, p2, best, bi, bpos, b2, nl2, b3);      // exact argmin over the two leaves, seeded with the old neighbour
+        if (l2 >= 0 && l2 != lf) leaf_eval<DIM>(bv.leaves + l2, l2, p2, best, bi, bpos, b2, nl2, b3);
+        lb_others = fminf(sqrtf(b2) * 0.999999f, lb3);                             // re-anchored here: the runner-up among the 16, or anything outside the two leaves
+        lb3 = fminf(sqrtf(b3) * 0.999999f, lb3);
+        l2 = nl2;
         need_walk = false;
     }
     // ---- the walks: shared over the wave (knn_walk_shared) -- the lanes whose queries verified, and those whose walks end early, take
@@ -146,28 +164,28 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
     // groups instead; the shared walk does that case as well, 0.0281 vs 0.0306 ms in iterations 10-16, and the kernel without the second
     // code path needs 68 instead of 80 VGPRs.)
 #if ICP_DEBUG_STEPS && !ICP_DEBUG_TIMES
-    if (k >= 0 && kp.dbg_steps) kp.dbg_steps[k] = need_walk ? -1 : leaf_only ? -2 : 0;      // -1: walk (overwritten with its length); -2: second tier, one leaf
+    if (k >= 0 && kp.dbg_steps) kp.dbg_steps[k] = need_walk ? -1 : leaf_only ? -2 : 0;      // -1: walk (overwritten with its length); -2: second tier, two leaves
 #endif
 #if ICP_SHARE_WALKS
     if (__any(need_walk)) {
         float rn[3] = {rn0, rn1, rn2};
-        knn_walk_shared<DIM, BVH_THREADS, typename std::conditional<WIDE, unsigned long long, unsigned int>::type>(bv, p, rn, need_walk, best, bi, bpos, lb_others, lb_outleaf, bvh_lbq, tid);
+        knn_walk_shared<DIM, BVH_THREADS, typename std::conditional<WIDE, unsigned long long, unsigned int>::type>(bv, p, rn, need_walk, best, bi, bpos, lb_others, lb3, l2, bvh_lbq, tid);
         rn0 = rn[0]; rn1 = rn[1]; rn2 = rn[2];
         q0 = -2;                                          // the neighbour's record is read again below: it need not stay in registers while this lane helps
     }
 #else
-    if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lb_outleaf, bvh_lbq, tid, (ICP_DEBUG_STEPS && kp.dbg_steps) ? kp.dbg_steps + k : nullptr);
+    if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lb3, l2, bvh_lbq, tid, (ICP_DEBUG_STEPS && kp.dbg_steps) ? kp.dbg_steps + k : nullptr);
 #endif
     ICP_STAMP(2);
 #if ICP_DEBUG_CUT
-    if (kp.nseg == 103) { if (k >= 0 && best == 123.f && lb_others == 77.f) pp.partials[0] = rn0 + rn1 + rn2 + lb_outleaf + ra.x + rb.x; return; }
+    if (kp.nseg == 103) { if (k >= 0 && best == 123.f && lb_others == 77.f) pp.partials[0] = rn0 + rn1 + rn2 + lb3 + ra.x + rb.x; return; }
 #endif
     if (k >= 0) {
         // A verified query keeps its stored anchor (position of the last full search) and bound: the triangle test stays valid
         // against the OLD anchor -- and is tighter than re-anchoring, (L - d1) - d2 <= L - |d1 + d2| -- and its neighbour is
         // unchanged, so nothing of its search state needs rewriting.  Once ICP has converged that is > 99.9 % of the queries:
         // the 28 B per query of state stores (and the Match record, when nobody reads it) disappear from those launches.
-        if (!verified) knn_store_state<DIM>(kp, k, p, best, bpos, lb_others, lb_outleaf);
+        if (!verified) knn_store_state<DIM>(kp, k, p, best, bpos, lb_others, lb3, l2);
         else if (kp.d2_out) kp.d2_out[k] = best;
         icp_match_t m;
         if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }

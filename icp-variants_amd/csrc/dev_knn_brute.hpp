@@ -27,7 +27,7 @@ struct KnnParams {
     int use_prev;                                            // 1: nn_raw holds the previous iteration's result for the same queries
     float4* qstate;                                          // [n] (query xyz when last searched or verified, lower bound on the distance to every OTHER target)
     int incremental;                                         // 1: verify-and-skip with qstate (needs use_prev)
-    float* qstate2;                                          // [n] lower bound, at the same anchor, on the distance to every target OUTSIDE the neighbour's leaf (second verification tier)
+    float2* qstate2;                                         // [n] (lower bound, at the same anchor, on every target outside the neighbour's leaf and the runner-up's leaf; that second leaf as int bits, -1: none)
     int* dbg_steps;                                          // development builds (ICP_DEBUG_STEPS): [n] nodes | leaves << 16 visited by the walk of query k; nullptr otherwise
 };
 

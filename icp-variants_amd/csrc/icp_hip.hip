@@ -486,8 +486,8 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr) {
 #endif
         if (p.knn_incremental && !q.pretransformed) {
             if ((rc = ensure(c, c->qstate, (size_t)q.n * 16))) return rc;
-            if ((rc = ensure(c, c->qstate2, (size_t)q.n * 4))) return rc;
-            kp.qstate = c->qstate.as<float4>(); kp.qstate2 = c->tier2 ? c->qstate2.as<float>() : nullptr; kp.incremental = 1;
+            if ((rc = ensure(c, c->qstate2, (size_t)q.n * 8))) return rc;
+            kp.qstate = c->qstate.as<float4>(); kp.qstate2 = c->tier2 ? c->qstate2.as<float2>() : nullptr; kp.incremental = 1;
         }
         const Cloud* fuse = (fused_blocks != nullptr && p.metric != ICP_METRIC_SYMMETRIC && !q.pretransformed) ? q.cl : nullptr;
         if (q.use_colors) return launch_bvh_query<6>(c, c->bvh6, target_coords6(c), kp, q.order, q.n, fuse, fused_blocks);

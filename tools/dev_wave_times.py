@@ -34,3 +34,13 @@ for iters in [int(a) for a in sys.argv[1:]] or [1, 3, 6, 12, 45]:
         print("  %-22s" % "  (phase lengths)" + "  ".join("%s: mean %.2f max %.2f" % (names[j + 1], d[:, j].mean(), d[:, j].max()) for j in range(5)))
     last = np.argsort(rel[:, 5])[-5:]
     for i in last: print("   late wave %5d: walkers %2d  stamps %s" % (i, walkers[i], np.round(rel[i], 2)))
+    # the queries that searched (walk or two-leaf tier) in this launch: records written by the launch itself (clock within its window)
+    rec = buf[nw * 8: nw * 8 + 8 * 4096].reshape(4096, 8)
+    clk = rec[:, 7].astype(np.uint32).astype(np.int64)
+    cur = rec[(clk >= t0) & (clk <= t[:, 5].max())]
+    f = lambda a: a.view(np.float32)
+    if len(cur) <= 64:
+        for r in cur:
+            best, lbo, lb3, delta = f(r[1:2])[0], f(r[2:3])[0], f(r[3:4])[0], f(r[4:5])[0]
+            print("   searched: k %6d %s sqrt(best) %.6g  bound on others %.6g  bound outside two leaves %.6g  moved %.3g  | margin tier1 %.3g  tier2 %.3g"
+                  % (r[0], "two-leaf l2=%d" % r[5] if r[5] != -2 else "walk", np.sqrt(best), lbo, lb3, delta, lbo - delta - np.sqrt(best), lb3 - delta - np.sqrt(best)))
