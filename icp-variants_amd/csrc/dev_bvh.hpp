@@ -658,11 +658,26 @@ __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<
 }
 
 // XCD-aware block mapping: workgroups are dealt round-robin over the 8 XCDs (block b runs on the XCD group b % 8), each
-// with a private 4 MiB L2.  With Morton-sorted queries, giving every XCD group ONE contiguous slice of the sorted list
-// means its L2 only has to hold the part of the tree under that slice (plus the shared top levels) instead of all of it.
-// (Measured in round 2 and dropped: slices of 8 / 32 consecutive blocks dealt round-robin instead -- balance against locality --
-// 20.7 k / 21.1 k vs 21.1 k iterations/s.)
+// with a private 4 MiB L2.  With Morton-sorted queries, giving an XCD consecutive blocks of the order means its L2 only has to hold
+// the part of the tree under them.  Round 1 gave every XCD ONE contiguous eighth of the order; but the hard queries (far from the
+// target, long walks) come in runs, so some eighths hold 1.5 x the work of others (per-slice walk time, tools/dev_wave_times.py)
+// and the launch waits for that XCD.  Chunks of 16 blocks (2048 queries) dealt to the XCDs in turn keep the locality and even out
+// the work: iterations 1-9 0.0615 -> 0.058 ms (chunks of 1 / 4 / 8 / 32 / 64: 0.061 / 0.0595 / 0.059 / 0.058 / 0.059).
+// Measured on top of that and dropped: a wave made of 2 / 4 / 8 / 16 runs of consecutive queries from as many places of its chunk
+// instead of 64 consecutive ones (evens out the waves, costs coherence: no gain beyond noise).
+#ifndef ICP_XCD_CHUNK
+#define ICP_XCD_CHUNK 16         // chunks of this many consecutive blocks dealt to the XCDs in turn; 0: one contiguous slice per XCD
+#endif
 __device__ __forceinline__ int xcd_contiguous_block(int b, int nb) {
+#if ICP_XCD_CHUNK
+    {
+        constexpr int C = ICP_XCD_CHUNK;
+        const int full = nb / (8 * C) * (8 * C);                      // the part of the grid that deals out evenly; the rest keeps its order
+        if (b >= full) return b;
+        const int x = b & 7, j = b >> 3;
+        return ((j / C) * 8 + x) * C + j % C;
+    }
+#endif
     const int q = nb >> 3, r = nb & 7, x = b & 7, j = b >> 3;        // XCD group x owns q (+1 if x < r) consecutive logical blocks
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
 }

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
         q0 = seeded ? kp.nn_raw[k] : -1;
         float4 st; st.x = 0.f; st.y = 0.f; st.z = 0.f; st.w = 0.f;
         float2 st2; st2.x = 0.f; st2.y = __int_as_float(-1);
-        if (inc) { st = kp.qstate[k]; if (kp.qstate2) st2 = kp.qstate2[k]; }
+        if (inc) st = kp.qstate[k];                        // (the second tier's 8 bytes are fetched only by the queries the first tier does not verify)
         xform_point(kp.ps->pose, r0, r1, r2, p[0], p[1], p[2]);
         if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
             need_walk = true;
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
                         // in -- is still provably farther than the old neighbour itself -> the nearest neighbour is one of their 16 points: two
                         // leaf evaluations instead of a walk.  This is what retires the queries that sit close to the bisector of two targets,
                         // which the first tier can never verify and which would otherwise walk in every iteration.
+                        if (kp.qstate2) st2 = kp.qstate2[k];
                         const float lb2 = (st2.x - delta) * 0.999999f;
                         if (sqrtf(best) * 1.000001f < lb2) { leaf_only = true; lb3 = lb2; l2 = __float_as_int(st2.y); }
                     }
