@@ -32,11 +32,11 @@ for iters in [int(a) for a in sys.argv[1:]] or [1, 3, 6, 12, 45]:
         print("  %-22s" % label + "  ".join("%s: mean %.2f p99 %.2f max %.2f" % (names[j], r[:, j].mean(), np.percentile(r[:, j], 99), r[:, j].max()) for j in range(6)))
         d = np.diff(r, axis=1)
         print("  %-22s" % "  (phase lengths)" + "  ".join("%s: mean %.2f max %.2f" % (names[j + 1], d[:, j].mean(), d[:, j].max()) for j in range(5)))
-    # the eight XCD slices of the launch order (xcd_contiguous_block): is one of them the tail?
-    nb = nw // 2; qx, rx = nb >> 3, nb & 7
-    starts = [x * (qx + 1) if x < rx else rx * (qx + 1) + (x - rx) * qx for x in range(9)]; starts[8] = nb
-    print("  per XCD slice: " + "  ".join("x%d: end mean %.1f max %.1f, walk-us sum %.0f" % (x, rel[2 * starts[x]:2 * starts[x + 1], 5].mean(), rel[2 * starts[x]:2 * starts[x + 1], 5].max(),
-                                                                                             (rel[2 * starts[x]:2 * starts[x + 1], 2] - rel[2 * starts[x]:2 * starts[x + 1], 1]).sum()) for x in range(8)))
+    # which XCD ran which logical block (xcd_contiguous_block with ICP_XCD_CHUNK = 16): is one of them the tail?
+    nb = nw // 2; C = 16; full = nb // (8 * C) * (8 * C)
+    lbs = np.arange(nb); xcd = np.where(lbs < full, (lbs // C) % 8, lbs % 8)
+    wx = np.repeat(xcd, 2)
+    print("  per XCD: " + "  ".join("x%d: end mean %.1f max %.1f, walk-us sum %.0f" % (x, rel[wx == x, 5].mean(), rel[wx == x, 5].max(), (rel[wx == x, 2] - rel[wx == x, 1]).sum()) for x in range(8)))
     last = np.argsort(rel[:, 5])[-5:]
     for i in last: print("   late wave %5d: walkers %2d  stamps %s" % (i, walkers[i], np.round(rel[i], 2)))
     # the queries that searched (walk or two-leaf tier) in this launch: records written by the launch itself (clock within its window)

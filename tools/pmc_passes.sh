@@ -19,11 +19,12 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sorted(glob.glob("$OUT/p*/*/*_counter_collection.csv")):
     for r in csv.DictReader(open(d)):
         agg[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
-with open("$OUT/summary.csv", "w") as f:
-    f.write("kernel,counter,mean_per_launch,launches\n")
+with open("$OUT/summary.csv", "w", newline="") as f:
+    wr = csv.writer(f)                                     # (template kernels have commas in their names: quoted)
+    wr.writerow(["kernel", "counter", "mean_per_launch", "launches"])
     for k in sorted(agg):
         if "icpdev" not in k: continue
         for c in sorted(agg[k]):
-            v = agg[k][c]; f.write("%s,%s,%.6g,%d\n" % (k, c, sum(v) / len(v), len(v)))
+            v = agg[k][c]; wr.writerow([k, c, "%.6g" % (sum(v) / len(v)), len(v)])
 print(open("$OUT/summary.csv").read())
 PY

@@ -22,14 +22,18 @@ cp $OUT/pmc/summary.csv $OUT/lbvh_pmc_summary.csv
 python - <<PY
 import csv, json
 rows = {(r["kernel"], r["counter"]): float(r["mean_per_launch"]) for r in csv.DictReader(open("$OUT/lbvh_pmc_summary.csv"))}
-k = [kk for (kk, c) in rows if "k_knn_bvh_post<3>" in kk][0]
+k = [kk for (kk, c) in rows if "k_knn_bvh_post<3" in kk][0]
 f, w = rows[(k, "FETCH_SIZE")], rows[(k, "WRITE_SIZE")]
 # MI355X_MICROARCH.md, HBM section: both counters are in KB; on gfx950 FETCH_SIZE tallies a 128-B request as 64 B -> doubled
-json.dump({"knn": "lbvh", "n_src": 370488, "kernel": "k_knn_bvh_post<3>", "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
+json.dump({"knn": "lbvh", "n_src": 370488, "kernel": "k_knn_bvh_post<3, false>", "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
            "fetch_size_kb_raw": f, "write_size_kb": w, "fetch_correction": "x2 (gfx950: FETCH_SIZE = TCC_EA0_RDREQ x 64 B against 128-B requests)",
            "source": "profiles/r02/lbvh_pmc_summary.csv: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes with --kernel-trace only "
                      "(tools/pmc_passes.sh lbvh 50), the 50 launches of one icp_run averaged"}, open("$OUT/traffic_latest.json", "w"))
 print(open("$OUT/traffic_latest.json").read())
 PY
+if [ -f icp-variants_amd/lib/libicp_hip_times.so ]; then      # development build with per-wave phase stamps (ICP_DEBUG_STEPS=1 ICP_DEBUG_TIMES=1), built before the call
+  echo "== wave phase times"
+  ICP_HIP_LIB=icp-variants_amd/lib/libicp_hip_times.so timeout -k 10 300 python tools/dev_wave_times.py 1 3 6 12 20 45 > $OUT/wave_phase_times.txt 2> $OUT/wave_phase_times.err
+fi
 rm -rf $OUT/kt $OUT/ktb $OUT/pmc/p*/
 echo done
