@@ -129,3 +129,54 @@ def test_fullsize_incremental_search_bit_identical(gpu_ctx_factory, eth_pair):
     for a, b in zip(res[0][0], res[1][0]):
         assert a["n_valid"] == b["n_valid"] and np.array_equal(a["pose"], b["pose"])
     assert res[0][1] < res[1][1]
+
+
+def test_fullsize_incremental_run_is_bit_identical_to_always_walk(gpu_ctx_factory, eth_pair):
+    """configs[1] at full size, 50 iterations: verify-and-skip (both tiers), shared walks and the spread start must not change a single
+    match -- every iteration's pose and valid count equal the run in which every query walks the tree in every iteration."""
+    out = []
+    for inc in (1, 0):
+        c = gpu_ctx_factory()
+        c.params.max_distance = 10.0; c.params.metric = 1; c.params.n_iterations = 50; c.params.knn_backend = 1; c.params.knn_incremental = inc
+        c.push_params()
+        c.set_target(eth_pair["tgt_pts"], eth_pair["tgt_nrm"]); c.set_source(eth_pair["src_pts"], eth_pair["src_nrm"])
+        _, recs, rc = c.run(np.eye(4))
+        assert rc == 0 and len(recs) == 50
+        out.append(recs)
+    for k, (a, b) in enumerate(zip(*out)):
+        assert a["n_valid"] == b["n_valid"] and np.array_equal(a["pose"], b["pose"]), k
+
+
+def test_deep_tree_over_524288_targets(gpu_ctx_factory, orc):
+    """A target of 603 120 points needs 9 levels of 4-wide nodes: the 64-bit pending mask and the <3, true> instance of the fused
+    matcher.  Matches bit-exact against the oracle's kd-tree, teacher-forced iterations within 1e-5, and the incremental run
+    bit-identical to the always-walk run."""
+    from conftest import pose_error
+    from icp_amd import synth
+    p = synth.eth_like_pair(1, n_tilt=560, n_beam=1077)
+    assert len(p["tgt_pts"]) == 603120
+    src, srn = p["src_pts"][::9], p["src_nrm"][::9]                     # 67 014 queries keep the oracle quick
+    c = gpu_ctx_factory()
+    c.params.max_distance = 10.0; c.params.metric = 1; c.params.n_iterations = 30; c.params.knn_backend = 1; c.push_params()
+    c.set_target(p["tgt_pts"], p["tgt_nrm"]); c.set_source(src, srn)
+    kd = orc.KdTree(p["tgt_pts"])
+    m, d2 = c.match(np.eye(4))
+    mo, do = kd.query(orc.transform_points(src, np.eye(4)), 10.0)
+    assert np.array_equal(m["idx"], mo["idx"]) and np.array_equal(d2.view(np.uint32), do.view(np.uint32))
+    prm = orc.make_params(metric=1, n_iterations=1, max_distance=10.0, solver_mode=1, knn_kdtree=1); prm.kdtree = kd.h
+    pose = np.eye(4, dtype=f32)
+    for k in range(3):
+        po, mo, nvo, _, _ = orc.iterate(prm, src, srn, None, p["tgt_pts"], p["tgt_nrm"], None, pose)
+        pg, st = c.iterate(pose)
+        assert st["n_valid"] == nvo
+        ang, tr = pose_error(pg, po)
+        assert ang < 1e-5 and tr < 1e-5, (k, ang, tr)
+        pose = po
+    out = []
+    for inc in (1, 0):
+        c.params.knn_incremental = inc; c.push_params()
+        _, recs, rc = c.run(np.eye(4))
+        assert rc == 0
+        out.append(recs)
+    for k, (a, b) in enumerate(zip(*out)):
+        assert a["n_valid"] == b["n_valid"] and np.array_equal(a["pose"], b["pose"]), k
