@@ -142,7 +142,9 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
     }
 #endif
 #if ICP_DEBUG_TIMES
-    if (kp.dbg_steps) { const int nw_ = __popcll(__ballot(need_walk && !leaf_only)), nl_ = __popcll(__ballot(leaf_only)); if (lane == 0) { kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + 6] = nw_; kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + 7] = nl_; } }
+    if (kp.dbg_steps) { const int nw_ = __popcll(__ballot(need_walk && !leaf_only)), nl_ = __popcll(__ballot(leaf_only)); if (lane == 0) { kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + 6] = nw_ | (nl_ << 8);
+            // where the wave runs: HW_ID (id 4: simd [5:4], cu [11:8], sh [12], se [15:13]) and XCC_ID (id 20) -> bits 16.. of the second word
+            kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + 7] = (int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu) | (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16)); } }
 #endif
 #if ICP_DEBUG_CUT
     if (kp.nseg == 102) { if (k >= 0 && best == 123.f && lb_others == 77.f) pp.partials[0] = rn0 + rn1 + rn2 + lb3; return; }

@@ -22,7 +22,9 @@ for iters in [int(a) for a in sys.argv[1:]] or [1, 3, 6, 12, 45]:
     t = w[:, :6].astype(np.uint32).astype(np.int64)
     t0 = t[:, 0].min()
     rel = (t - t0) * 0.01                                     # us since the first wave started
-    walkers = w[:, 6]; leaf_only = w[:, 7]
+    walkers = w[:, 6] & 0xFF; leaf_only = (w[:, 6] >> 8) & 0xFF
+    hw = w[:, 7].astype(np.uint32)
+    simd = ((hw >> 16) & 0xF).astype(np.int64) * 4096 + ((hw >> 13) & 7) * 512 + ((hw >> 12) & 1) * 256 + ((hw >> 8) & 0xF) * 4 + ((hw >> 4) & 3)      # (xcc, se, sh, cu, simd)
     names = ["start", "front", "walks", "post", "reduce", "end"]
     print("iteration %d: %d waves, %d with walkers (%d walking queries), %d leaf-only queries; launch spans %.2f us from the first stamp"
           % (iters - 1, nw, (walkers > 0).sum(), walkers.sum(), leaf_only.sum(), rel[:, 5].max()))
@@ -32,9 +34,23 @@ for iters in [int(a) for a in sys.argv[1:]] or [1, 3, 6, 12, 45]:
         print("  %-22s" % label + "  ".join("%s: mean %.2f p99 %.2f max %.2f" % (names[j], r[:, j].mean(), np.percentile(r[:, j], 99), r[:, j].max()) for j in range(6)))
         d = np.diff(r, axis=1)
         print("  %-22s" % "  (phase lengths)" + "  ".join("%s: mean %.2f max %.2f" % (names[j + 1], d[:, j].mean(), d[:, j].max()) for j in range(5)))
+    # per SIMD: when its last wave ends, how much wave time it held -- is the launch waiting for a few SIMDs (balance) or for all of them (latency)?
+    ids, inv = np.unique(simd, return_inverse=True)
+    s_end = np.zeros(len(ids)); np.maximum.at(s_end, inv, rel[:, 5])
+    s_cnt = np.bincount(inv); s_busy = np.bincount(inv, weights=rel[:, 5] - rel[:, 0])
+    print("  per SIMD (%d seen, %.1f waves each): last wave ends mean %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f us; wave-time held mean %.0f max %.0f us"
+          % (len(ids), s_cnt.mean(), s_end.mean(), np.percentile(s_end, 10), np.percentile(s_end, 50), np.percentile(s_end, 90), s_end.max(), s_busy.mean(), s_busy.max()))
+    cu = simd // 4
+    cids, cinv = np.unique(cu, return_inverse=True)
+    c_end = np.zeros(len(cids)); np.maximum.at(c_end, cinv, rel[:, 5])
+    c_mean = np.bincount(cinv, weights=rel[:, 5]) / np.bincount(cinv)
+    print("  per CU (%d seen): last wave ends mean %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f us; mean wave end per CU: min %.1f  p50 %.1f  max %.1f"
+          % (len(cids), c_end.mean(), np.percentile(c_end, 10), np.percentile(c_end, 50), np.percentile(c_end, 90), c_end.max(), c_mean.min(), np.percentile(c_mean, 50), c_mean.max()))
+    xc = simd // 4096
+    print("  per XCD as placed by the hardware: " + "  ".join("x%d: %d waves, mean end %.1f, last %.1f" % (x, (xc == x).sum(), rel[xc == x, 5].mean(), rel[xc == x, 5].max()) for x in np.unique(xc)))
     # which XCD ran which logical block (xcd_contiguous_block with ICP_XCD_CHUNK = 16): is one of them the tail?
-    nb = nw // 2; C = 16; full = nb // (8 * C) * (8 * C)
-    lbs = np.arange(nb); xcd = np.where(lbs < full, (lbs // C) % 8, lbs % 8)
+    nb = nw // 2; CH = 16; full = nb // (8 * CH) * (8 * CH)
+    lbs = np.arange(nb); xcd = np.where(lbs < full, (lbs // CH) % 8, lbs % 8)
     wx = np.repeat(xcd, 2)
     print("  per XCD: " + "  ".join("x%d: end mean %.1f max %.1f, walk-us sum %.0f" % (x, rel[wx == x, 5].mean(), rel[wx == x, 5].max(), (rel[wx == x, 2] - rel[wx == x, 1]).sum()) for x in range(8)))
     last = np.argsort(rel[:, 5])[-5:]
