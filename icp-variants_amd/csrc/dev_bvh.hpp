@@ -446,6 +446,12 @@ __device__ __forceinline__ f2 pair_lb(const BvhNodeT<DIM>* __restrict__ nd, cons
     return acc;
 }
 
+// Square roots for BOUNDS: one v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence (17 instructions), with the rounding
+// absorbed by the safety factor every bound carries anyway (1e-6 = 8 ulp).  sqrt_up never underestimates -- a denormal argument, which
+// the instruction may flush to zero, is raised to FLT_MIN first; sqrt_dn never overestimates (a flush to zero is a valid lower bound).
+__device__ __forceinline__ float sqrt_up(float x) { return __builtin_amdgcn_sqrtf(fmaxf(x, 1.17549435e-38f)) * 1.000001f; }
+__device__ __forceinline__ float sqrt_dn(float x) { return __builtin_amdgcn_sqrtf(x) * 0.999999f; }
+
 // What a search remembers about the points that did NOT win, for next iteration's verify tests: b2 = the smallest distance among them
 // and l2 = the leaf that point lives in (the runner-up's leaf; it can be the winner's own leaf), b3 = a lower bound on the non-winners
 // outside leaf l2.  An entry is (distance, leaf); entries of leaf l2 other than the runner-up itself may or may not reach b3 -- either
@@ -710,9 +716,9 @@ __device__ __forceinline__ bool knn_try_verify(const KnnParams& kp, const BvhVie
     if (kp.incremental && kp.use_prev && bi >= 0) {
         const float4 s = kp.qstate[k];
         const float ex = p[0] - s.x, ey = p[1] - s.y, ez = p[2] - s.z;
-        const float delta = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.000001f + 1e-30f;
+        const float delta = sqrt_up((ex * ex + ey * ey) + ez * ez);
         const float lbn = (s.w - delta) * 0.999999f;
-        if (sqrtf(best) * 1.000001f < lbn) { lb_others = lbn; return true; }
+        if (sqrt_up(best) < lbn) { lb_others = lbn; return true; }
     }
     return false;
 }
@@ -931,8 +937,8 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
         const float rest = fminf(__uint_as_float(b.x), sk);
         // (a winner dethroned during the merge went straight to the rest: it can be nearer than the runner-up entry.  No entry at all: the
         //  initial key reads as a NaN distance and fminf returns the other operand)
-        lb_others = sqrtf(fminf(__uint_as_float((unsigned int)(key2 >> 32)), rest)) * 0.999999f;
-        lb3 = sqrtf(rest) * 0.999999f;
+        lb_others = sqrt_dn(fminf(__uint_as_float((unsigned int)(key2 >> 32)), rest));
+        lb3 = sqrt_dn(rest);
         l2o = key2 == ~0ull ? -1 : (int)(unsigned int)key2;
     } else {
         const uint2 a = R[3 * NT + lane], b = R[4 * NT + lane], c = R[5 * NT + lane];
@@ -988,8 +994,8 @@ __device__ __forceinline__ float knn_walk(const BvhViewT<DIM>& bv, const float* 
     if (dbg_out) *dbg_out = dbg_nodes | (dbg_leaves << 16);
 #endif
     asm volatile("" ::"v"(touched));
-    lb3 = sqrtf(fminf(b3, minlb)) * 0.999999f;
-    return sqrtf(fminf(b2, minlb)) * 0.999999f;
+    lb3 = sqrt_dn(fminf(b3, minlb));
+    return sqrt_dn(fminf(b2, minlb));
 }
 
 // One query per lane (k < 0: none), the whole wave together: the lanes without a walk of their own help with the others'.

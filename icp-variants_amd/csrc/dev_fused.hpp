@@ -6,13 +6,13 @@
 // accumulates it, so matches never make a round trip through memory.  One kernel instead of two per iteration.  Each lane
 // has at most one pair: its contributions are produced two at a time and fed straight into the first step of the transposing
 // wave reduction, which keeps the kernel at the register budget of the walk.  Block partials keep the fixed-order contract.
-struct RowSlotGen {                                       // value A = slot A of one pair's point-to-plane rows
-    const RowTerms& R; bool valid;
+struct RowSlotGen {                                       // value A = slot A of one pair's point-to-plane rows (a lane without a pair: all-zero rows)
+    const RowTerms& R;
     static constexpr int N = 27;
-    template <int A> __device__ __forceinline__ double get() const { return valid ? row_slot<A>(R) : 0.0; }
+    template <int A> __device__ __forceinline__ double get() const { return row_slot<A>(R); }
 };
 struct P2pGen {                                           // values 0..21 = sum s (3), sum d (3), then SUM_M + 0..15 of post_core's point-to-point block
-    float s[3], d[3]; double wd; bool valid;
+    float s[3], d[3]; double wd;
     static constexpr int N = 22;
     template <int A> __device__ __forceinline__ double get() const {
         double v;
@@ -22,7 +22,7 @@ struct P2pGen {                                           // values 0..21 = sum 
         else if constexpr (A < 10) v = wd * s[A - 7];
         else if constexpr (A < 13) v = wd * d[A - 10];
         else v = (double)d[(A - 13) / 3] * (wd * s[(A - 13) % 3]);
-        return valid ? v : 0.0;
+        return v;
     }
 };
 // Measured and NOT adopted (round 2): folding the block partials and solving INSIDE this launch (two levels of "last arriver
@@ -115,12 +115,12 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
                 if (d < best) { best = d; bi = j0; bpos = q0; }
                 if (inc && bi >= 0) {
                     const float ex = p[0] - st.x, ey = p[1] - st.y, ez = p[2] - st.z;
-                    const float delta = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.000001f + 1e-30f;
+                    const float delta = sqrt_up((ex * ex + ey * ey) + ez * ez), sbest = sqrt_up(best);
                     const float lbn = (st.w - delta) * 0.999999f;
 #if ICP_DEBUG_TIMES
                     dbg_lbo = st.w; dbg_lb3 = st2.x; dbg_delta = delta;
 #endif
-                    if (sqrtf(best) * 1.000001f < lbn) { lb_others = lbn; need_walk = false; verified = true; }
+                    if (sbest < lbn) { lb_others = lbn; need_walk = false; verified = true; }
                     else {
                         // second tier: every target outside TWO leaves -- the neighbour's and the one the runner-up of the last search lives
                         // in -- is still provably farther than the old neighbour itself -> the nearest neighbour is one of their 16 points: two
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
                         // which the first tier can never verify and which would otherwise walk in every iteration.
                         if (kp.qstate2) st2 = kp.qstate2[k];
                         const float lb2 = (st2.x - delta) * 0.999999f;
-                        if (sqrtf(best) * 1.000001f < lb2) { leaf_only = true; lb3 = lb2; l2 = __float_as_int(st2.y); }
+                        if (sbest < lb2) { leaf_only = true; lb3 = lb2; l2 = __float_as_int(st2.y); }
                     }
                 }
             }
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
         const int lf = q0 >> 3;
         leaf_eval<DIM>(bv.leaves + lf, lf, p2, best, bi, bpos, b2, nl2, b3);      // exact argmin over the two leaves, seeded with the old neighbour
         if (l2 >= 0 && l2 != lf) leaf_eval<DIM>(bv.leaves + l2, l2, p2, best, bi, bpos, b2, nl2, b3);
-        lb_others = fminf(sqrtf(b2) * 0.999999f, lb3);                             // re-anchored here: the runner-up among the 16, or anything outside the two leaves
-        lb3 = fminf(sqrtf(b3) * 0.999999f, lb3);
+        lb_others = fminf(sqrt_dn(b2), lb3);                             // re-anchored here: the runner-up among the 16, or anything outside the two leaves
+        lb3 = fminf(sqrt_dn(b3), lb3);
         l2 = nl2;
         need_walk = false;
     }
@@ -210,13 +210,15 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
     // LDS, and threads 0..33 write the block partial in the fixed slot order the reducer expects.
     double* lds = (double*)bvh_lbq;                       // [NW][32] wave totals, then [NW] counts
     double tot;
+    // a lane without a valid pair contributes zeros: its INPUTS are zeroed (10 selects) rather than each of its 27 contributions (54)
+    if (!valid) { s0 = 0.f; s1 = 0.f; s2 = 0.f; d0 = 0.f; d1 = 0.f; d2 = 0.f; n0 = 0.f; n1 = 0.f; n2 = 0.f; wt = 0.f; }
     if (pp.metric == ICP_METRIC_POINT_TO_PLANE) {
         RowTerms R;
         build_rows(0, s0, s1, s2, d0, d1, d2, n0, n1, n2, wt, R);
-        const RowSlotGen g{R, valid};                     // 27 slots of [J^T J | J^T r]
+        const RowSlotGen g{R};                            // 27 slots of [J^T J | J^T r]
         tot = wave_transpose_reduce_gen<6, 0>(g, lane);
     } else {                                              // point-to-point moments (see post_core): sum s, sum d, then the 16 weighted ones
-        const P2pGen g{{s0, s1, s2}, {d0, d1, d2}, (double)wt, valid};
+        const P2pGen g{{s0, s1, s2}, {d0, d1, d2}, (double)wt};
         tot = wave_transpose_reduce_gen<6, 0>(g, lane);
     }
     ICP_STAMP(4);
