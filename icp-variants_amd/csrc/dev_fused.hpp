@@ -65,6 +65,18 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
                  "s"(pp.max_dist), "s"(pp.cos_reject), "s"(pp.partials), "s"(gridDim.x));
 #endif
     constexpr int NW = BVH_THREADS / WAVE;
+    // Pose and normal matrix through the constant address space: wave-uniform and unchanged for the length of the launch (k_reduce_solve
+    // wrote them before it), so they can be SCALAR loads, issued here with the arguments, instead of per-lane vector loads that the
+    // compiler places behind the wait for the query's own loads (one more dependent trip in front of every launch) and keeps in 21 VGPRs.
+    typedef const __attribute__((address_space(4))) float* cfloat_p;
+    float Pm[16], Nm[9];
+    {
+        const cfloat_p pc = (cfloat_p)(const void*)kp.ps->pose; const cfloat_p nc = (cfloat_p)(const void*)kp.ps->nmat;
+#pragma unroll
+        for (int q = 0; q < 16; q++) Pm[q] = pc[q];
+#pragma unroll
+        for (int q = 0; q < 9; q++) Nm[q] = nc[q];
+    }
     ICP_CUT(1);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int t0 = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS;
@@ -97,7 +109,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
         float4 st; st.x = 0.f; st.y = 0.f; st.z = 0.f; st.w = 0.f;
         float2 st2; st2.x = 0.f; st2.y = __int_as_float(-1);
         if (inc) st = kp.qstate[k];                        // (the second tier's 8 bytes are fetched only by the queries the first tier does not verify)
-        xform_point(kp.ps->pose, r0, r1, r2, p[0], p[1], p[2]);
+        xform_point(Pm, r0, r1, r2, p[0], p[1], p[2]);
         if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
             need_walk = true;
             if (q0 >= 0) {                                 // seed_from_previous + knn_try_verify, on the batched loads
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
             if (DIM != 3 || bpos != q0) { ra = *(const float4*)(bv.recs + bpos); rb = *((const float4*)(bv.recs + bpos) + 1); }      // one 32-byte record
             d0 = ra.x; d1 = ra.y; d2 = ra.z; n0 = rb.x; n1 = rb.y; n2 = rb.z;
             s0 = p[0]; s1 = p[1]; s2 = p[2];
-            valid = post_eval<true>(pp, k, m, d0, d1, d2, n0, n1, n2, __float_as_uint(rb.w), s0, s1, s2, wt, rn0, rn1, rn2);
+            valid = post_eval<true>(pp, k, m, d0, d1, d2, n0, n1, n2, __float_as_uint(rb.w), s0, s1, s2, wt, rn0, rn1, rn2, Nm);
         }
     }
     ICP_STAMP(3);

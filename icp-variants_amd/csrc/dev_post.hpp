@@ -222,9 +222,9 @@ struct PostParams {
 // whether the pair enters the system, with the transformed source point and the weight.  post_core adds the system build.
 template <bool HAVE_S = false>
 __device__ __forceinline__ bool post_eval(const PostParams& pp, int k, icp_match_t m, float d0, float d1, float d2, float nt0, float nt1, float nt2, uint32_t tcol,
-                                          float& s0, float& s1, float& s2, float& w, float rn0 = 0.f, float rn1 = 0.f, float rn2 = 0.f) {
+                                          float& s0, float& s1, float& s2, float& w, float rn0 = 0.f, float rn1 = 0.f, float rn2 = 0.f, const float* nmat = nullptr) {
     const float* __restrict__ P = pp.ps->pose;
-    const float* __restrict__ N = pp.ps->nmat;
+    const float* __restrict__ N = nmat ? nmat : pp.ps->nmat;      // (the fused matcher hands over the copy it fetched with scalar loads)
     const int i = pp.sel ? pp.sel[k] : k;
     float ns0, ns1, ns2;
     if (!HAVE_S) {                                         // HAVE_S: the matcher passes the transformed point and the raw source normal
