@@ -163,21 +163,23 @@ template <int A>
 __device__ __forceinline__ double row_slot(const RowTerms& R) {
     constexpr int ta = A < 6 ? 0 : A < 11 ? 1 : A < 15 ? 2 : A < 18 ? 3 : A < 20 ? 4 : A < 21 ? 5 : A - 21;      // row index a (or a of J^T r)
     constexpr int tc = A < 21 ? ta + (A - (ta * 6 - ta * (ta - 1) / 2)) : 6;                                      // column c (6 = rhs)
+    // (the product of two fp32 values is exact in fp64 -- 48 significant bits -- so fma(a, b, v) rounds the same sum as a * b followed by + v:
+    //  one instruction instead of two, bit-identical)
     double v = (double)R.r0[ta] * (double)R.r0[tc];
     // row 1: entries at columns 1 (p1), 2 (p2), 3 (g), rhs rr1
     {
         constexpr bool ha = ta == 1 || ta == 2 || ta == 3, hc = tc == 1 || tc == 2 || tc == 3 || tc == 6;
-        if (ha && hc) v += (double)(ta == 1 ? R.p1 : ta == 2 ? R.p2 : R.g) * (double)(tc == 1 ? R.p1 : tc == 2 ? R.p2 : tc == 3 ? R.g : R.rr1);
+        if (ha && hc) v = fma((double)(ta == 1 ? R.p1 : ta == 2 ? R.p2 : R.g), (double)(tc == 1 ? R.p1 : tc == 2 ? R.p2 : tc == 3 ? R.g : R.rr1), v);
     }
     // row 2: columns 0 (q0), 2 (q2), 4 (g), rhs rr2
     {
         constexpr bool ha = ta == 0 || ta == 2 || ta == 4, hc = tc == 0 || tc == 2 || tc == 4 || tc == 6;
-        if (ha && hc) v += (double)(ta == 0 ? R.q0 : ta == 2 ? R.q2 : R.g) * (double)(tc == 0 ? R.q0 : tc == 2 ? R.q2 : tc == 4 ? R.g : R.rr2);
+        if (ha && hc) v = fma((double)(ta == 0 ? R.q0 : ta == 2 ? R.q2 : R.g), (double)(tc == 0 ? R.q0 : tc == 2 ? R.q2 : tc == 4 ? R.g : R.rr2), v);
     }
     // row 3: columns 0 (t0), 1 (t1), 5 (g), rhs rr3
     {
         constexpr bool ha = ta == 0 || ta == 1 || ta == 5, hc = tc == 0 || tc == 1 || tc == 5 || tc == 6;
-        if (ha && hc) v += (double)(ta == 0 ? R.t0 : ta == 1 ? R.t1 : R.g) * (double)(tc == 0 ? R.t0 : tc == 1 ? R.t1 : tc == 5 ? R.g : R.rr3);
+        if (ha && hc) v = fma((double)(ta == 0 ? R.t0 : ta == 1 ? R.t1 : R.g), (double)(tc == 0 ? R.t0 : tc == 1 ? R.t1 : tc == 5 ? R.g : R.rr3), v);
     }
     return v;
 }
