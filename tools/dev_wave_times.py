@@ -48,6 +48,16 @@ for iters in [int(a) for a in sys.argv[1:]] or [1, 3, 6, 12, 45]:
           % (len(cids), c_end.mean(), np.percentile(c_end, 10), np.percentile(c_end, 50), np.percentile(c_end, 90), c_end.max(), c_mean.min(), np.percentile(c_mean, 50), c_mean.max()))
     xc = simd // 4096
     print("  per XCD as placed by the hardware: " + "  ".join("x%d: %d waves, mean end %.1f, last %.1f" % (x, (xc == x).sum(), rel[xc == x, 5].mean(), rel[xc == x, 5].max()) for x in np.unique(xc)))
+    if os.environ.get("ICP_DEV_PLACEMENT"):                # how does the dispatcher place consecutive hardware blocks?  (XCD, CU) of blocks 0, 8, 16, ... (the ones XCD 0 gets)
+        nbk = nw // 2; CHK = 16; fullk = nbk // (8 * CHK) * (8 * CHK)
+        def logical(b):
+            if b >= fullk: return b
+            x, j = b & 7, b >> 3
+            return ((j // CHK) * 8 + x) * CHK + j % CHK
+        seq = [(int(simd[2 * logical(b)] // 4096), int((simd[2 * logical(b)] // 4) % 1024)) for b in range(0, 8 * 80, 8)]
+        print("  placement of hardware blocks 0, 8, 16, ...: " + " ".join("%d:%d" % s_ for s_ in seq))
+        seq1 = [(int(simd[2 * logical(b)] // 4096), int((simd[2 * logical(b)] // 4) % 1024)) for b in range(0, 24)]
+        print("  placement of hardware blocks 0..23: " + " ".join("%d:%d" % s_ for s_ in seq1))
     # which XCD ran which logical block (xcd_contiguous_block with ICP_XCD_CHUNK = 16): is one of them the tail?
     nb = nw // 2; CH = 16; full = nb // (8 * CH) * (8 * CH)
     lbs = np.arange(nb); xcd = np.where(lbs < full, (lbs // CH) % 8, lbs % 8)
