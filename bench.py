@@ -271,8 +271,8 @@ def load_workload(args, binding, synth, rank, ctx):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--iterations", type=int, default=50, help="ICP iterations per step (main.cpp:366)")
     ap.add_argument("--knn", choices=["brute", "lbvh"], default=os.environ.get("ICP_BENCH_KNN", "lbvh"))
     ap.add_argument("--n-tilt", type=int, default=344)
