@@ -94,7 +94,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
 #if ICP_DEBUG_TIMES
     float dbg_lbo = 0.f, dbg_lb3 = 0.f, dbg_delta = 0.f;
 #endif
-    bool need_walk = false, verified = false, leaf_only = false;
+    bool need_walk = false, verified = false, two_leaf = false;
     float lb3 = 0.f; int l2 = -1;                         // second verification tier: bound on every target outside the neighbour's leaf and the runner-up's leaf l2
     if (k >= 0) {
         // ---- front end.  Everything that depends only on the query index is requested in ONE batch (point, normal, previous
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
                         // which the first tier can never verify and which would otherwise walk in every iteration.
                         if (kp.qstate2) st2 = kp.qstate2[k];
                         const float lb2 = (st2.x - delta) * 0.999999f;
-                        if (sbest < lb2) { leaf_only = true; lb3 = lb2; l2 = __float_as_int(st2.y); }
+                        if (sbest < lb2) { two_leaf = true; lb3 = lb2; l2 = __float_as_int(st2.y); }
                     }
                 }
             }
@@ -148,20 +148,20 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
     }
     ICP_STAMP(1);
 #if ICP_DEBUG_TIMES
-    if (kp.dbg_steps && k >= 0 && (need_walk || leaf_only) && kp.use_prev) {      // who is it that still searches?  (slot by query index; the clock tells the launch)
+    if (kp.dbg_steps && k >= 0 && (need_walk || two_leaf) && kp.use_prev) {      // who is it that still searches?  (slot by query index; the clock tells the launch)
         int* r = kp.dbg_steps + 8 * (gridDim.x * NW) + 8 * (k & 4095);
-        r[0] = k; r[1] = __float_as_int(best); r[2] = __float_as_int(dbg_lbo); r[3] = __float_as_int(dbg_lb3); r[4] = __float_as_int(dbg_delta); r[5] = leaf_only ? l2 : -2; r[6] = q0; r[7] = (int)(unsigned int)wall_clock64();
+        r[0] = k; r[1] = __float_as_int(best); r[2] = __float_as_int(dbg_lbo); r[3] = __float_as_int(dbg_lb3); r[4] = __float_as_int(dbg_delta); r[5] = two_leaf ? l2 : -2; r[6] = q0; r[7] = (int)(unsigned int)wall_clock64();
     }
 #endif
 #if ICP_DEBUG_TIMES
-    if (kp.dbg_steps) { const int nw_ = __popcll(__ballot(need_walk && !leaf_only)), nl_ = __popcll(__ballot(leaf_only)); if (lane == 0) { kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + 6] = nw_ | (nl_ << 8);
+    if (kp.dbg_steps) { const int nw_ = __popcll(__ballot(need_walk && !two_leaf)), nl_ = __popcll(__ballot(two_leaf)); if (lane == 0) { kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + 6] = nw_ | (nl_ << 8);
             // where the wave runs: HW_ID (id 4: simd [5:4], cu [11:8], sh [12], se [15:13]) and XCC_ID (id 20) -> bits 16.. of the second word
             kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + 7] = (int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu) | (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16)); } }
 #endif
 #if ICP_DEBUG_CUT
     if (kp.nseg == 102) { if (k >= 0 && best == 123.f && lb_others == 77.f) pp.partials[0] = rn0 + rn1 + rn2 + lb3; return; }
 #endif
-    if (leaf_only) {
+    if (two_leaf) {
         f2 p2[DIM];
 #pragma unroll
         for (int q = 0; q < DIM; q++) { p2[q].x = p[q]; p2[q].y = p[q]; }
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
     // groups instead; the shared walk does that case as well, 0.0281 vs 0.0306 ms in iterations 10-16, and the kernel without the second
     // code path needs 68 instead of 80 VGPRs.)
 #if ICP_DEBUG_STEPS && !ICP_DEBUG_TIMES
-    if (k >= 0 && kp.dbg_steps) kp.dbg_steps[k] = need_walk ? -1 : leaf_only ? -2 : 0;      // -1: walk (overwritten with its length); -2: second tier, two leaves
+    if (k >= 0 && kp.dbg_steps) kp.dbg_steps[k] = need_walk ? -1 : two_leaf ? -2 : 0;      // -1: walk (overwritten with its length); -2: second tier, two leaves
 #endif
 #if ICP_SHARE_WALKS
     if (__any(need_walk)) {

@@ -1172,7 +1172,8 @@ static int transform_common(icp_ctx* c, const float* in, int32_t n, const float 
     return guard.done();
 }
 // Development builds (ICP_DEBUG_STEPS=1): nodes | leaves << 16 visited by the walk of each query of the LAST matcher launch, in the
-// order the launch indexed its queries (Morton order for a run); 0 = verified without a walk, -1 = cooperative search.
+// order the launch indexed its queries (Morton order for a run); 0 = verified without a walk, -2 = second tier (two leaves), -1 = a walk whose length was not recorded.  Per-query lengths need
+// ICP_SHARE_WALKS=0 (a shared walk has no per-query length); with ICP_DEBUG_TIMES=1 the buffer holds per-wave phase stamps instead (tools/dev_wave_times.py).
 int icp_debug_steps(icp_ctx* c, int32_t* out, int32_t n) {
     if (!c || !out || n <= 0 || !c->dbg_steps.p || (size_t)n * 4 > c->dbg_steps.cap) return ICP_ERR_INVALID_ARG;
     int rc;

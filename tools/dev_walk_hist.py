@@ -1,4 +1,4 @@
-"""Dev tool (needs the ICP_DEBUG_STEPS build: ICP_HIP_LIB=.../libicp_hip_dbg.so): distribution of the tree-walk length per query
+"""Dev tool (needs a build with ICP_DEBUG_STEPS=1 ICP_SHARE_WALKS=0 -- a shared walk has no per-query length --: ICP_HIP_LIB=.../libicp_hip_dbg.so): distribution of the tree-walk length per query
 and per wave for chosen ICP iterations of configs[1].  usage: ICP_HIP_LIB=... python tools/dev_walk_hist.py"""
 import sys, os, ctypes as C
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
@@ -17,13 +17,13 @@ for iters in (1, 2, 3, 5, 9, 13, 20, 40):
     buf = np.zeros(n, np.int32)
     rc = c.lib.icp_debug_steps(c.h, buf.ctypes.data_as(C.c_void_p), C.c_int32(n))
     assert rc == 0, rc
-    coop = buf == -2; ver = buf == 0       # -2: second verification tier (one leaf); 0: verified or taken by the cooperative search
+    tier2 = buf == -2; ver = buf == 0       # -2: second verification tier (two leaves); 0: verified
     nodes = np.where(buf > 0, buf & 0xFFFF, 0); leaves = np.where(buf > 0, buf >> 16, 0); tot = nodes + leaves
     w = tot[: (n // 64) * 64].reshape(-1, 64)
     wmax = w.max(1); wsum = w.sum(1)
     walk = tot[tot > 0]
     pct = lambda a, q: [int(x) for x in np.percentile(a, q)] if len(a) else []
-    print("iteration %2d: verified/coop %6d leaf-only %6d walked %6d | per query nodes mean %.1f leaves mean %.1f total pct[50,90,99,99.9,100] %s | "
+    print("iteration %2d: verified %6d two-leaf tier %6d walked %6d | per query nodes mean %.1f leaves mean %.1f total pct[50,90,99,99.9,100] %s | "
           "per wave: max-lane pct[50,90,99,100] %s, lane utilisation %.2f, waves with max > 40: %d of %d"
-          % (iters - 1, ver.sum(), coop.sum(), len(walk), nodes[tot > 0].mean() if len(walk) else 0, leaves[tot > 0].mean() if len(walk) else 0,
+          % (iters - 1, ver.sum(), tier2.sum(), len(walk), nodes[tot > 0].mean() if len(walk) else 0, leaves[tot > 0].mean() if len(walk) else 0,
              pct(walk, [50, 90, 99, 99.9, 100]), pct(wmax, [50, 90, 99, 100]), wsum.sum() / max(1, (wmax * 64).sum()), (wmax > 40).sum(), len(wmax)), flush=True)

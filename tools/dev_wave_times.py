@@ -22,12 +22,12 @@ for iters in [int(a) for a in sys.argv[1:]] or [1, 3, 6, 12, 45]:
     t = w[:, :6].astype(np.uint32).astype(np.int64)
     t0 = t[:, 0].min()
     rel = (t - t0) * 0.01                                     # us since the first wave started
-    walkers = w[:, 6] & 0xFF; leaf_only = (w[:, 6] >> 8) & 0xFF
+    walkers = w[:, 6] & 0xFF; two_leaf = (w[:, 6] >> 8) & 0xFF
     hw = w[:, 7].astype(np.uint32)
     simd = ((hw >> 16) & 0xF).astype(np.int64) * 4096 + ((hw >> 13) & 7) * 512 + ((hw >> 12) & 1) * 256 + ((hw >> 8) & 0xF) * 4 + ((hw >> 4) & 3)      # (xcc, se, sh, cu, simd)
     names = ["start", "front", "walks", "post", "reduce", "end"]
-    print("iteration %d: %d waves, %d with walkers (%d walking queries), %d leaf-only queries; launch spans %.2f us from the first stamp"
-          % (iters - 1, nw, (walkers > 0).sum(), walkers.sum(), leaf_only.sum(), rel[:, 5].max()))
+    print("iteration %d: %d waves, %d with walkers (%d walking queries), %d queries in the two-leaf tier; launch spans %.2f us from the first stamp"
+          % (iters - 1, nw, (walkers > 0).sum(), walkers.sum(), two_leaf.sum(), rel[:, 5].max()))
     for label, m in (("all waves", np.ones(nw, bool)), ("waves without walkers", walkers == 0), ("waves with walkers", walkers > 0)):
         if not m.any(): continue
         r = rel[m]
