@@ -25,6 +25,8 @@ for iters in [int(a) for a in sys.argv[1:]] or [1, 3, 6, 12, 45]:
     walkers = w[:, 6] & 0xFF; two_leaf = (w[:, 6] >> 8) & 0xFF
     hw = w[:, 7].astype(np.uint32)
     simd = ((hw >> 16) & 0xF).astype(np.int64) * 4096 + ((hw >> 13) & 7) * 512 + ((hw >> 12) & 1) * 256 + ((hw >> 8) & 0xF) * 4 + ((hw >> 4) & 3)      # (xcc, se, sh, cu, simd)
+    if os.environ.get("ICP_DEV_DUMP"):                     # raw per-wave arrays for offline what-if analyses
+        np.savez(os.path.join(os.environ["ICP_DEV_DUMP"], "waves_it%d.npz" % (iters - 1)), rel=rel, simd=simd, walkers=walkers)
     names = ["start", "front", "walks", "post", "reduce", "end"]
     print("iteration %d: %d waves, %d with walkers (%d walking queries), %d queries in the two-leaf tier; launch spans %.2f us from the first stamp"
           % (iters - 1, nw, (walkers > 0).sum(), walkers.sum(), two_leaf.sum(), rel[:, 5].max()))
