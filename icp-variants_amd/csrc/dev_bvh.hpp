@@ -31,7 +31,9 @@
 #define ICP_PRUNE_SLACK 1.001f
 #endif
 #ifndef ICP_PREFETCH_PATH
-#define ICP_PREFETCH_PATH 1
+// 1: a seeded walk first touches the nodes of its seed's root-to-leaf path (quad_prefetch_path).  It paid while every lane walked alone
+// (round 1 / early round 2); with the shared walk it no longer does (iterations 1-9 0.0567 ms without, 0.0578 with): off.
+#define ICP_PREFETCH_PATH 0
 #endif
 constexpr int BVH_LEAF = 8;
 #ifndef ICP_BVH_THREADS
