@@ -49,21 +49,9 @@ struct P2pGen {                                           // values 0..21 = sum 
 #else
 #define ICP_STAMP(j)
 #endif
-#ifndef ICP_KERNARG_UPFRONT
-#define ICP_KERNARG_UPFRONT 1
-#endif
 template <int DIM, bool WIDE>      // WIDE: trees deeper than 8 levels of 4-wide nodes (> 524 288 targets) keep 64 pending bits per lane
 __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {
     extern __shared__ uint2 bvh_lbq[];                    // [ICP_SHARE_ROWS][BVH_THREADS]: the shared walk's records; reused by the reduction
-#if ICP_KERNARG_UPFRONT
-    // The ~480 bytes of arguments are 8 cache lines; the compiler fetches each field where it is first used, behind branches, i.e. in
-    // half a dozen scalar-load-then-wait rounds spread over the front end -- and at the start of a launch every one of them misses.
-    // Naming the fields of the all-lanes path here makes them ONE batch of scalar loads and one wait.
-    asm volatile("" :: "s"(kp.sx), "s"(kp.sy), "s"(kp.sz), "s"(kp.sel), "s"(kp.n), "s"(kp.ps), "s"(kp.max_dist), "s"(kp.nn_raw), "s"(kp.use_prev),
-                 "s"(kp.qstate), "s"(kp.incremental), "s"(kp.qstate2), "s"(kp.d2_out), "s"(qorder), "s"(bv.recs), "s"(bv.n_valid), "s"(bv.Lq),
-                 "s"(pp.snx), "s"(pp.sny), "s"(pp.snz), "s"(pp.sel), "s"(pp.matches), "s"(pp.metric), "s"(pp.weighting), "s"(pp.rejection),
-                 "s"(pp.max_dist), "s"(pp.cos_reject), "s"(pp.partials), "s"(gridDim.x));
-#endif
     constexpr int NW = BVH_THREADS / WAVE;
     // Pose and normal matrix through the constant address space: wave-uniform and unchanged for the length of the launch (k_reduce_solve
     // wrote them before it), so they can be SCALAR loads, issued here with the arguments, instead of per-lane vector loads that the
