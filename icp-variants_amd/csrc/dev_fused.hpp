@@ -187,7 +187,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
         // A verified query keeps its stored anchor (position of the last full search) and bound: the triangle test stays valid
         // against the OLD anchor -- and is tighter than re-anchoring, (L - d1) - d2 <= L - |d1 + d2| -- and its neighbour is
         // unchanged, so nothing of its search state needs rewriting.  Once ICP has converged that is > 99.9 % of the queries:
-        // the 28 B per query of state stores (and the Match record, when nobody reads it) disappear from those launches.
+        // the 32 B per query of state stores (and the Match record, when nobody reads it) disappear from those launches.
         if (!verified) knn_store_state<DIM>(kp, k, p, best, bpos, lb_others, lb3, l2);
         else if (kp.d2_out) kp.d2_out[k] = best;
         icp_match_t m;
