@@ -49,16 +49,22 @@ struct P2pGen {                                           // values 0..21 = sum 
 #else
 #define ICP_STAMP(j)
 #endif
-template <int DIM, bool WIDE>      // WIDE: trees deeper than 8 levels of 4-wide nodes (> 524 288 targets) keep 64 pending bits per lane
-__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {
+// MERGED: the launch of iteration i carries the reducer of iteration i - 1 in its first rp.n_red blocks and every matcher block waits
+// for the pose they publish (dev_solve.hpp, "the ring form") -- AFTER it has issued the loads that do not need the pose.
+template <int DIM, bool WIDE, bool MERGED>      // WIDE: trees deeper than 8 levels of 4-wide nodes (> 524 288 targets) keep 64 pending bits per lane
+__device__ __forceinline__ void fused_matcher_body(const KnnParams& kp, const BvhViewT<DIM>& bv, const int* __restrict__ qorder, const PostParams& pp, const RingParams& rp) {
     extern __shared__ uint2 bvh_lbq[];                    // [ICP_SHARE_ROWS][BVH_THREADS]: the shared walk's records; reused by the reduction
     constexpr int NW = BVH_THREADS / WAVE;
+    if constexpr (MERGED) { if ((int)blockIdx.x < rp.n_red) { ring_reduce_solve(rp); return; } }
+    const int n_red = MERGED ? rp.n_red : 0;
+    const int mblock = (int)blockIdx.x - n_red, mgrid = (int)gridDim.x - n_red;      // this block / the grid among the matcher blocks
     // Pose and normal matrix through the constant address space: wave-uniform and unchanged for the length of the launch (k_reduce_solve
     // wrote them before it), so they can be SCALAR loads, issued here with the arguments, instead of per-lane vector loads that the
     // compiler places behind the wait for the query's own loads (one more dependent trip in front of every launch) and keeps in 21 VGPRs.
+    // (MERGED: they arrive through ring_wait_pose below, into scalar registers as well.)
     typedef const __attribute__((address_space(4))) float* cfloat_p;
     float Pm[16], Nm[9];
-    {
+    if constexpr (!MERGED) {
         const cfloat_p pc = (cfloat_p)(const void*)kp.ps->pose; const cfloat_p nc = (cfloat_p)(const void*)kp.ps->nmat;
 #pragma unroll
         for (int q = 0; q < 16; q++) Pm[q] = pc[q];
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
     }
     ICP_CUT(1);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int t0 = xcd_contiguous_block(blockIdx.x, gridDim.x) * BVH_THREADS;
+    const int t0 = xcd_contiguous_block(mblock, mgrid) * BVH_THREADS;
     const int t = t0 + tid;
     ICP_STAMP(0);
     const int k = (t < kp.n) ? (qorder ? qorder[t] : t) : -1;
@@ -84,31 +90,40 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
 #endif
     bool need_walk = false, verified = false, two_leaf = false;
     float lb3 = 0.f; int l2 = -1;                         // second verification tier: bound on every target outside the neighbour's leaf and the runner-up's leaf l2
+    // ---- front end.  Everything that depends only on the query index is requested in ONE batch (point, normal, previous
+    // neighbour, search state), then the neighbour's record: two memory round trips before the verify test instead of
+    // one per array -- in the late iterations, where almost no query walks, those round trips ARE the kernel.  None of it needs the
+    // pose: in the merged loop all of it is in flight while the reducer blocks in front of this grid fold and solve.
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    float4 st; st.x = 0.f; st.y = 0.f; st.z = 0.f; st.w = 0.f;
+    float tq[DIM]; int j0 = -1;
+#pragma unroll
+    for (int q = 0; q < DIM; q++) tq[q] = 0.f;
+    const bool seeded = kp.use_prev != 0, inc = kp.incremental && seeded;
     if (k >= 0) {
-        // ---- front end.  Everything that depends only on the query index is requested in ONE batch (point, normal, previous
-        // neighbour, search state), then the neighbour's record: two memory round trips before the verify test instead of
-        // one per array -- in the late iterations, where almost no query walks, those round trips ARE the kernel.
         const int i = kp.sel ? kp.sel[k] : k;
-        const float r0 = kp.sx[i], r1 = kp.sy[i], r2 = kp.sz[i];
+        r0 = kp.sx[i]; r1 = kp.sy[i]; r2 = kp.sz[i];
         if (DIM == 6) { p[3 % DIM] = kp.scr[i]; p[4 % DIM] = kp.scg[i]; p[5 % DIM] = kp.scb[i]; }
         rn0 = pp.snx[i]; rn1 = pp.sny[i]; rn2 = pp.snz[i];
-        const bool seeded = kp.use_prev != 0, inc = kp.incremental && seeded;
         q0 = seeded ? kp.nn_raw[k] : -1;
-        float4 st; st.x = 0.f; st.y = 0.f; st.z = 0.f; st.w = 0.f;
-        float2 st2; st2.x = 0.f; st2.y = __int_as_float(-1);
         if (inc) st = kp.qstate[k];                        // (the second tier's 8 bytes are fetched only by the queries the first tier does not verify)
+        if (q0 >= 0) {
+            if (DIM == 3) { ra = *(const float4*)(bv.recs + q0); rb = *((const float4*)(bv.recs + q0) + 1); tq[0] = ra.x; tq[1] = ra.y; tq[2] = ra.z; j0 = __float_as_int(ra.w); }
+            else {
+                const BvhLeafT<DIM>* lf = bv.leaves + (q0 >> 3);
+#pragma unroll
+                for (int q = 0; q < DIM; q++) tq[q] = lf->c[q][q0 & 7];
+                j0 = lf->idx[q0 & 7];
+            }
+        }
+    }
+    if constexpr (MERGED) { if (!ring_wait_pose(kp.ps, lane, rp.run_fault, Pm, Nm)) return; }
+    if (k >= 0) {
+        float2 st2; st2.x = 0.f; st2.y = __int_as_float(-1);
         xform_point(Pm, r0, r1, r2, p[0], p[1], p[2]);
         if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
             need_walk = true;
             if (q0 >= 0) {                                 // seed_from_previous + knn_try_verify, on the batched loads
-                float tq[DIM]; int j0;
-                if (DIM == 3) { ra = *(const float4*)(bv.recs + q0); rb = *((const float4*)(bv.recs + q0) + 1); tq[0] = ra.x; tq[1] = ra.y; tq[2] = ra.z; j0 = __float_as_int(ra.w); }
-                else {
-                    const BvhLeafT<DIM>* lf = bv.leaves + (q0 >> 3);
-#pragma unroll
-                    for (int q = 0; q < DIM; q++) tq[q] = lf->c[q][q0 & 7];
-                    j0 = lf->idx[q0 & 7];
-                }
                 float d = 0.f;
 #pragma unroll
                 for (int q = 0; q < DIM; q++) { const float e = p[q] - tq[q]; d = (q == 0) ? e * e : d + e * e; }
@@ -137,7 +152,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
     ICP_STAMP(1);
 #if ICP_DEBUG_TIMES
     if (kp.dbg_steps && k >= 0 && (need_walk || two_leaf) && kp.use_prev) {      // who is it that still searches?  (slot by query index; the clock tells the launch)
-        int* r = kp.dbg_steps + 8 * (gridDim.x * NW) + 8 * (k & 4095);
+        int* r = kp.dbg_steps + 8 * (mgrid * NW) + 8 * (k & 4095);
         r[0] = k; r[1] = __float_as_int(best); r[2] = __float_as_int(dbg_lbo); r[3] = __float_as_int(dbg_lb3); r[4] = __float_as_int(dbg_delta); r[5] = two_leaf ? l2 : -2; r[6] = q0; r[7] = (int)(unsigned int)wall_clock64();
     }
 #endif
@@ -232,7 +247,7 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
         if (lane == 0) lds[NW * 32 + w] = (double)__popcll(vm);
     }
     __syncthreads();
-    const int nb = gridDim.x, lb = t0 / BVH_THREADS;                              // partial slot = logical block -> fixed summation order
+    const int nb = mgrid, lb = t0 / BVH_THREADS;                                  // partial slot = logical block -> fixed summation order
     if (tid < NSUM_USED) {                                // threads 0..33: this block's sum `tid`
         double out = 0.0;
         if (tid == SUM_N) { for (int ww = 0; ww < NW; ww++) out += lds[NW * 32 + ww]; }
@@ -246,4 +261,16 @@ __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp
         pp.partials[(size_t)tid * nb + lb] = out;
     }
     ICP_STAMP(5);
+}
+template <int DIM, bool WIDE>
+__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {
+    const RingParams none{};
+    fused_matcher_body<DIM, WIDE, false>(kp, bv, qorder, pp, none);
+}
+// The merged loop's launch: blocks [0, rp.n_red) = reducer of the previous iteration, the rest = this iteration's matcher (kp.ps = the
+// pose slot they wait for).
+template <int DIM, bool WIDE>
+__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post_ring(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp, const RingParams rp) {
+    static_assert(BVH_THREADS == RING_THREADS, "the reducer blocks share the matcher's block size");
+    fused_matcher_body<DIM, WIDE, true>(kp, bv, qorder, pp, rp);
 }

@@ -241,16 +241,15 @@ struct SolveParams {
 // Point-to-plane fast path of k_reduce_solve on the lanes of the (last) block instead of one thread: the same LDL^T recurrences
 // as solve_ldlt6 (every element sees the same operations in the same order, so the result is bit-identical to it), the three
 // sincos on three lanes, the pose product on sixteen.  A single lane runs ~13 cycles per dependent fp64 operation with nothing
-// to overlap; this cuts the serial tail of every iteration from ~5 us to ~2 us.  Returns false (nothing written) when it does not
-// apply: other metrics, no valid pair, or a pivot fails the rank test -> the caller's single-thread path with the eigen fallback.
-// All threads of the block must call it.
-__device__ __forceinline__ bool solve_p2plane_lanes(const SolveParams& sp, const double* tot /* shared */) {
+// to overlap; this cuts the serial tail of every iteration from ~5 us to ~2 us.
+// p2plane_lanes_core: m = the 27 point-to-plane sums (shared memory), pose_in = the pose the iteration searched at (16 floats, global or
+// shared).  Returns the composed pose dT * pose_in (16 floats in shared memory, valid for every thread after the call) or nullptr when
+// a pivot fails the rank test (nothing computed).  All threads of the block must call it (>= 64 threads).
+__device__ __forceinline__ const float* p2plane_lanes_core(const double* m /* shared */, const float* pose_in) {
     __shared__ double A[6][7], Lm[6][6], od[6], xs[6];
     __shared__ float scs[6], dTs[16], npose[16];
     __shared__ int okflag;
-    if (!(sp.update_pose && sp.metric == ICP_METRIC_POINT_TO_PLANE && sp.phase == 0 && tot[SUM_N] > 0)) return false;   // uniform
     const int tid = threadIdx.x, i = tid / 7, j = tid % 7;
-    const double* m = tot + SUM_M;
     if (tid < 42) A[i][j] = (j == 6) ? m[21 + i] : (j >= i ? m[i * 6 - i * (i - 1) / 2 + (j - i)] : 0.0);
     if (tid < 6) od[tid] = m[tid * 6 - tid * (tid - 1) / 2];
     if (tid == 0) okflag = 1;
@@ -267,13 +266,8 @@ __device__ __forceinline__ bool solve_p2plane_lanes(const SolveParams& sp, const
         __syncthreads();
     }
     __syncthreads();
-    if (!okflag) return false;
-    PoseState* ps = sp.ps;
+    if (!okflag) return nullptr;
     if (tid == 0) {
-        if (sp.sums_out) for (int a = 0; a < NSUM; a++) sp.sums_out[a] = tot[a];
-        // means are not needed for this metric; keep the state defined (k_reduce_solve's phase 0 writes them too)
-        const double n = tot[SUM_N];
-        for (int k = 0; k < 3; k++) { ps->mean_s[k] = (float)(tot[SUM_S + k] / n); ps->mean_d[k] = (float)(tot[SUM_D + k] / n); }
         double x[6];
         for (int r = 5; r >= 0; r--) {                   // D y = z ; L^T x = y
             double v = A[r][6] / A[r][r];
@@ -297,13 +291,29 @@ __device__ __forceinline__ bool solve_p2plane_lanes(const SolveParams& sp, const
     __syncthreads();
     if (tid < 16) {                                       // mat4_mul_f32(dT, pose): column-major, sequential over k
         const int c = tid >> 2, r = tid & 3;
-        float acc = dTs[0 * 4 + r] * ps->pose[c * 4 + 0];
-        acc = acc + dTs[1 * 4 + r] * ps->pose[c * 4 + 1];
-        acc = acc + dTs[2 * 4 + r] * ps->pose[c * 4 + 2];
-        acc = acc + dTs[3 * 4 + r] * ps->pose[c * 4 + 3];
+        float acc = dTs[0 * 4 + r] * pose_in[c * 4 + 0];
+        acc = acc + dTs[1 * 4 + r] * pose_in[c * 4 + 1];
+        acc = acc + dTs[2 * 4 + r] * pose_in[c * 4 + 2];
+        acc = acc + dTs[3 * 4 + r] * pose_in[c * 4 + 3];
         npose[tid] = acc;
     }
     __syncthreads();
+    return npose;
+}
+// The k_reduce_solve form: pose state updated in place.  Returns false (nothing written) when the fast path does not apply: other
+// metrics, no valid pair, or a pivot fails the rank test -> the caller's single-thread path with the eigen fallback.
+__device__ __forceinline__ bool solve_p2plane_lanes(const SolveParams& sp, const double* tot /* shared */) {
+    if (!(sp.update_pose && sp.metric == ICP_METRIC_POINT_TO_PLANE && sp.phase == 0 && tot[SUM_N] > 0)) return false;   // uniform
+    PoseState* ps = sp.ps;
+    const float* npose = p2plane_lanes_core(tot + SUM_M, ps->pose);
+    if (!npose) return false;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        if (sp.sums_out) for (int a = 0; a < NSUM; a++) sp.sums_out[a] = tot[a];
+        // means are not needed for this metric; keep the state defined (k_reduce_solve's phase 0 writes them too)
+        const double n = tot[SUM_N];
+        for (int k = 0; k < 3; k++) { ps->mean_s[k] = (float)(tot[SUM_S + k] / n); ps->mean_d[k] = (float)(tot[SUM_D + k] / n); }
+    }
     if (tid < 16) { ps->pose[tid] = npose[tid]; if (sp.stats) sp.stats->pose[tid] = npose[tid]; }
     if (tid == 32) normal_matrix_from_pose(npose, ps->nmat);
     if (tid == 33 && sp.stats) {
@@ -502,3 +512,151 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
 // Measured and NOT adopted (round 2): the same reduction + solve as ONE block of 1024 threads for producers that leave few partials
 // (k_post's 512; the fused matcher with 512-thread blocks, 724 partials) -- no hand-over between blocks, but 8.1-9.0 us against
 // 7.4 us for the 34-block form (and the matcher itself is slower with 256- / 512-thread blocks: 22.1 k / 20.3 k vs 22.6 k it/s).
+
+// ---- the ring form: reduce + solve of iteration i - 1 riding IN FRONT of the matcher launch of iteration i ---------------------
+// k_reduce_solve is a launch of its own: 6.7 us per iteration, 2.4 of them the bare cost of a dependent launch, behind a matcher whose
+// own launch costs the same -- a fifth of a converged run.  In the merged loop (point-to-plane through the fused BVH matcher, see
+// run_loop) blocks 0..NSUM_USED-1 of the matcher grid of iteration i ARE the reducer of iteration i - 1: they are dispatched first and
+// wait for nothing that comes after them, so the matcher blocks behind them may wait for their result without a deadlock.  The matcher
+// blocks issue every load that does not need the pose (source point, normal, search state, previous neighbour's record), and only then
+// wait for the pose: one launch per iteration, with reduce + solve hidden behind the matcher's own load burst.
+//   Hand-overs, all of the "self-validating 8-byte granule" kind (MI355X_MICROARCH.md, hand-off price list: handoff-1to1 -- one
+//   naturally aligned 8-byte sc1 store per granule, sc1-load polls, no fence, no flag, no ordering between granules):
+//   * totals: reducer block a -> block 0, slot a of THIS iteration's row of the totals ring;
+//   * pose:   block 0 -> every matcher block, the 16 granules (128 bytes) of THIS iteration's slot of the pose ring.
+//   Both rings are filled with all-ones (hipMemsetAsync 0xFF) at the start of every run, and a slot is written exactly once per run:
+//   "not written yet" is the one bit pattern no writer stores (a writer flips the lowest bit of a value that happens to equal it), and
+//   nothing has to be re-armed -- a run that was cut short leaves nothing behind that the next run could mistake for a result.
+//   Every wait is bounded (SPIN_LIMIT polls, seconds): a waiter that gives up raises *run_fault and the host repeats the run with the
+//   separate k_reduce_solve launches.  The same happens (PoseState::fault = 2 in the published slot, the rest of the chain passes it on
+//   without touching anything) when a pivot of the 6 x 6 system fails the rank test, i.e. when the solve needs the eigen fallback that
+//   only k_reduce_solve carries (131 VGPRs: it must not ride in the matcher).
+constexpr unsigned long long GRANULE_EMPTY = ~0ull;
+#ifndef ICP_RING_SLEEP
+#define ICP_RING_SLEEP 4           // s_sleep argument (x 64 clocks) between two polls of the pose slot by a matcher wave
+#endif
+struct RingParams {
+    const double* red_partials; int red_nblocks;   // partials of the iteration being reduced: [NSUM][red_nblocks]
+    unsigned long long* totals_row;                // [NSUM] that iteration's row of the totals ring
+    const PoseState* ps_in;                        // the pose that iteration searched at: complete since the previous launch
+    PoseState* ps_out;                             // slot to publish: the pose the matcher blocks of THIS launch wait for
+    icp_iter_stats* stats; int n_src;              // record of the reduced iteration
+    int* run_fault;                                // raised by any waiter that ran out of polls
+    int n_red;                                     // reducer blocks in front of this grid: 0 (first launch of a run) or NSUM_USED
+};
+__device__ __forceinline__ unsigned long long granule_of(unsigned int lo, unsigned int hi) {
+    const unsigned long long g = ((unsigned long long)hi << 32) | lo;
+    return g == GRANULE_EMPTY ? g ^ 1ull : g;             // (all-ones is a NaN pair either way)
+}
+// All threads of reducer block a = blockIdx.x < NSUM_USED; blockDim.x == RING_THREADS (two waves).  The fold reproduces k_reduce_solve's
+// summation order exactly -- thread t stands for the threads t and t + 128 of its 256-thread block: same strided assignment, same
+// shuffle trees, the four wave sums added in the same order -- so the merged loop and the separate launches give bit-identical poses
+// (tests/test_gpu_merged.py compares them).
+constexpr int RING_THREADS = 128;
+__device__ __forceinline__ void ring_reduce_solve(const RingParams& rp) {
+    __shared__ double tot[NSUM];
+    __shared__ double wsum[4];
+    __shared__ unsigned int slot_words[32];
+    __shared__ int give_up;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, a = blockIdx.x;
+    if (a == 0 && rp.ps_in->fault) {                      // the chain was cut further up: pass it on, touch nothing else
+        if (tid < 16) { const unsigned int* src = (const unsigned int*)rp.ps_in; __hip_atomic_store((unsigned long long*)rp.ps_out + tid, granule_of(src[2 * tid], src[2 * tid + 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        return;
+    }
+    {
+        const double* __restrict__ row = rp.red_partials + (size_t)a * rp.red_nblocks;
+        double x0 = 0.0, x1 = 0.0;                          // virtual threads tid and tid + 128 of the 256-thread fold
+        for (int b0 = 0; b0 < rp.red_nblocks; b0 += SOLVE_INFLIGHT * SOLVE_THREADS) {
+            double v0[SOLVE_INFLIGHT], v1[SOLVE_INFLIGHT];
+#pragma unroll
+            for (int j = 0; j < SOLVE_INFLIGHT; j++) {
+                const int b = b0 + j * SOLVE_THREADS + tid;
+                v0[j] = b < rp.red_nblocks ? row[b] : 0.0;
+                v1[j] = b + RING_THREADS < rp.red_nblocks ? row[b + RING_THREADS] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < SOLVE_INFLIGHT; j++) {
+                const int b = b0 + j * SOLVE_THREADS + tid;
+                if (b < rp.red_nblocks) x0 += v0[j];
+                if (b + RING_THREADS < rp.red_nblocks) x1 += v1[j];
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) { x0 += __shfl_down(x0, off, WAVE); x1 += __shfl_down(x1, off, WAVE); }
+        if (lane == 0) { wsum[w] = x0; wsum[2 + w] = x1; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double x = wsum[0];
+        for (int k = 1; k < 4; k++) x += wsum[k];
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+        __hip_atomic_store(rp.totals_row + a, granule_of((unsigned int)bits, (unsigned int)(bits >> 32)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (a != 0) return;
+    if (tid == 0) give_up = 0;
+    __syncthreads();
+    if (tid < NSUM) {
+        double v = 0.0;
+        if (tid < NSUM_USED) {
+            unsigned long long bits = GRANULE_EMPTY;
+            for (int spin = 0; spin < SPIN_LIMIT; spin++) {
+                bits = __hip_atomic_load(rp.totals_row + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (bits != GRANULE_EMPTY) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (bits == GRANULE_EMPTY) give_up = 1;         // never written within the bound
+            v = __longlong_as_double((long long)bits);
+        }
+        tot[tid] = v;
+    }
+    __syncthreads();
+    const PoseState* pin = rp.ps_in;
+    const double n = tot[SUM_N];
+    int fault = 0, status = ICP_OK;
+    const float* npose = nullptr;
+    if (give_up) { fault = 1; if (tid == 0) atomicOr(rp.run_fault, 1); }
+    else if (n > 0) { npose = p2plane_lanes_core(tot + SUM_M, pin->pose); if (!npose) fault = 2; }      // (uniform: every thread of the block takes the same branch)
+    else status = ICP_ERR_NO_CORRESPONDENCES;              // the pose stays (ICPOptimizer.h:668,680: the reference would hang in ASSERT)
+    // the slot: pose, normal matrix, means, fault -- assembled in LDS, published as 16 granules
+    if (tid < 16) slot_words[tid] = __float_as_uint(npose ? npose[tid] : pin->pose[tid]);
+    if (tid == 32) {
+        float nm[9];
+        if (npose) normal_matrix_from_pose(npose, nm); else for (int q = 0; q < 9; q++) nm[q] = pin->nmat[q];
+        for (int q = 0; q < 9; q++) slot_words[16 + q] = __float_as_uint(nm[q]);
+    }
+    if (tid == 33) {
+        for (int k = 0; k < 3; k++) {
+            slot_words[25 + k] = __float_as_uint(n > 0 ? (float)(tot[SUM_S + k] / n) : 0.f);
+            slot_words[28 + k] = __float_as_uint(n > 0 ? (float)(tot[SUM_D + k] / n) : 0.f);
+        }
+        slot_words[31] = (unsigned int)fault;
+    }
+    __syncthreads();
+    if (tid < 16) __hip_atomic_store((unsigned long long*)rp.ps_out + tid, granule_of(slot_words[2 * tid], slot_words[2 * tid + 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (rp.stats && !fault) {                             // the record of the reduced iteration (read by the host after the run)
+        if (tid < 16) rp.stats->pose[tid] = __uint_as_float(slot_words[tid]);
+        if (tid == 16) { rp.stats->n_src = rp.n_src; rp.stats->n_valid = (int)n; rp.stats->rmse = -1.f; rp.stats->benchmark_error = -1.f; rp.stats->status = status; }
+    }
+}
+// The reducer alone: closes a merged run (the last iteration has no matcher launch behind it to ride in).
+__global__ __launch_bounds__(RING_THREADS) void k_ring_reduce_solve(const RingParams rp) { ring_reduce_solve(rp); }
+
+// The matcher side of the pose hand-over: lanes 0..15 of the wave poll the 16 granules of the slot until none is empty, then the
+// pose and the normal matrix move to scalar registers.  Returns false when the wait ran out (*run_fault raised) or the slot carries
+// a fault: the caller's block leaves without writing anything.
+__device__ __forceinline__ bool ring_wait_pose(const PoseState* slot, int lane, int* run_fault, float (&Pm)[16], float (&Nm)[9]) {
+    const unsigned long long* g = (const unsigned long long*)slot;
+    unsigned long long v = 0ull;
+    bool ok = false;
+    for (int spin = 0; spin < SPIN_LIMIT; spin++) {
+        if (lane < 16) v = __hip_atomic_load(g + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!__any(lane < 16 && v == GRANULE_EMPTY)) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(ICP_RING_SLEEP);
+    }
+    if (!ok) { if (lane == 0) atomicOr(run_fault, 1); return false; }
+    const int lo = (int)(unsigned int)v, hi = (int)(unsigned int)(v >> 32);
+#pragma unroll
+    for (int q = 0; q < 16; q++) Pm[q] = __int_as_float(__builtin_amdgcn_readlane((q & 1) ? hi : lo, q >> 1));
+#pragma unroll
+    for (int q = 0; q < 9; q++) Nm[q] = __int_as_float(__builtin_amdgcn_readlane(((16 + q) & 1) ? hi : lo, (16 + q) >> 1));
+    return __builtin_amdgcn_readlane(hi, 15) == 0;
+}

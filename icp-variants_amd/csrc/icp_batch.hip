@@ -11,6 +11,7 @@
 // Only the public C ABI of icp_hip.h is used here (a context is driven exactly as a C++14 host would drive it).
 // =====================================================================================
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -93,21 +94,29 @@ bool load_rccl() {
     // the system stack this library already pulled in -- and an RCCL on the other stack finds "no ROCm-capable device".
     void* h = nullptr;
     Dl_info di;
-    if (dladdr((const void*)&hipGetDeviceCount, &di) && di.dli_fname) {
-        std::string dir(di.dli_fname);
-        const size_t slash = dir.rfind('/');
-        if (slash != std::string::npos) {
-            dir.resize(slash + 1);
-            h = dlopen((dir + "librccl.so.1").c_str(), RTLD_NOW | RTLD_GLOBAL);
-            if (!h) h = dlopen((dir + "librccl.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
+    const char* forced = getenv("ICP_HIP_RCCL_LIB");      // tests / unusual installations: this file and nothing else
+    if (forced && forced[0]) h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+    else {
+        if (dladdr((const void*)&hipGetDeviceCount, &di) && di.dli_fname) {
+            std::string dir(di.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                h = dlopen((dir + "librccl.so.1").c_str(), RTLD_NOW | RTLD_GLOBAL);
+                if (!h) h = dlopen((dir + "librccl.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
+            }
         }
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     }
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) { g_err = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return false; }
+    if (!h) {
+        const char* e = dlerror();                          // (one call: it returns the message AND clears it)
+        g_err = std::string(forced && forced[0] ? "ICP_HIP_RCCL_LIB could not be loaded: " : "librccl.so.1 not found: ") + (e ? e : "no further detail from the loader");
+        return false;
+    }
     Rccl r; r.h = h;
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");

@@ -78,6 +78,9 @@ struct icp_ctx {
     bool presort = true;                 // BVH build: upper levels from presorted axes (ICP_HIP_PRESORT=0: one global sort per level)
     bool trace = false;                  // ICP_HIP_TRACE=1: per-iteration stage times on stderr
     bool fuse_post = true;               // BVH matcher runs weight / reject / accumulate as its epilogue (ICP_HIP_FUSE_POST=0 disables)
+    bool merge_loop = true;              // point-to-plane loop through the fused BVH matcher: reduce + solve ride in front of the next matcher launch (ICP_HIP_MERGE=0: separate k_reduce_solve launches)
+    int merged_runs = 0, merged_fallbacks = 0;   // runs that took the merged loop / that had to be repeated with the separate launches (icp_debug_counters)
+    bool keep_fused_records = false;     // icp_match_seeded: the fused matcher also writes its Match records and distances (the loop itself never reads them)
     icp_params prm;
     Cloud tgt, src, qry;                 // qry: scratch cloud of icp_query_matches
     Cloud nrm_cloud; Bvh nrm_bvh;        // scratch of icp_estimate_normals
@@ -93,7 +96,7 @@ struct icp_ctx {
 #if ICP_DEBUG_CUT
     int dbg_iter = -1;             // development build: the launch of this iteration is cut short (ICP_HIP_DBG_CUT / ICP_HIP_DBG_CUT_ITER) to time its phases
 #endif
-    DevBuf ps, matches, d2, best64, nn_raw, partials, totals, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
+    DevBuf ps, matches, d2, best64, nn_raw, partials, partials2, ring, totals, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
     Cloud conv_src, conv_ref; int conv_n = 0;
     float cos_reject = 0.5f;
     std::vector<hipEvent_t> events;
@@ -255,6 +258,9 @@ int write_pose(icp_ctx* c, const float pose[16]) {
     HIPCK(c, hipMemcpyAsync(c->ps.p, h, sizeof(*h), hipMemcpyHostToDevice, c->stream));
     return ICP_OK;
 }
+
+// One launch of the merged loop: the pose slot its matcher blocks wait for, where they leave their partials, and the reducer that rides in front.
+struct MergeLaunch { RingParams rp; const PoseState* slot; double* partials; };
 
 struct QuerySet { const Cloud* cl; const int* sel; int n; int pretransformed; bool use_colors; bool seed_prev; const int* order; };   // cl/sel: also what the post stage reads
 
@@ -423,7 +429,7 @@ PostParams make_post_params(icp_ctx* c, const Cloud& src, const int* sel, int n)
 // fuse != nullptr: run the post stage (weight / reject / accumulate) as the epilogue of the search; *fused_blocks receives the
 // number of block partials written.
 template <int DIM>
-int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnParams& kp, const int* order, int n, const Cloud* fuse, int* fused_blocks) {
+int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnParams& kp, const int* order, int n, const Cloud* fuse, int* fused_blocks, const MergeLaunch* ml = nullptr) {
     int rc;
     if (!b.valid && (rc = build_bvh<DIM>(c, b, cp))) return rc;
     BvhViewT<DIM> bv; bv.leaves = b.leaves.as<BvhLeafT<DIM>>(); bv.nodes = b.nodes.as<BvhNodeT<DIM>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
@@ -433,14 +439,19 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
     if (fuse) {
         if ((rc = ensure(c, c->partials, (size_t)(nb > POST_BLOCKS ? nb : POST_BLOCKS) * NSUM * 8))) return rc;
         PostParams pp = make_post_params(c, *fuse, kp.sel, n);
-        pp.matches = nullptr;                                                     // the loop never reads the records of a fused iteration
-        KnnParams kf = kp; kf.d2_out = nullptr; kf.out = nullptr;                 // ... nor the distances
+        KnnParams kf = kp; kf.out = nullptr;
+        if (!c->keep_fused_records) { pp.matches = nullptr; kf.d2_out = nullptr; }     // the loop never reads the records of a fused iteration, nor the distances
 #if ICP_DEBUG_CUT
         { const char* e = getenv("ICP_HIP_DBG_CUT"); const char* f = getenv("ICP_HIP_DBG_CUT_ITER"); kf.nseg = (e && f && atoi(f) == c->dbg_iter) ? 100 + atoi(e) : 1; }
 #endif
         const size_t red_bytes = (size_t)(BVH_THREADS / WAVE) * 33 * 8;           // the reduction reuses the (dead) traversal stacks
         const size_t lds = stack_bytes > red_bytes ? stack_bytes : red_bytes;
-        if (b.Lq <= 8) hipLaunchKernelGGL((k_knn_bvh_post<DIM, false>), dim3(nb), dim3(BVH_THREADS), lds, c->stream, kf, bv, order, pp);
+        if (ml) {                                                                  // merged loop: reducer blocks in front, pose through the ring
+            kf.ps = ml->slot; pp.ps = ml->slot; pp.partials = ml->partials;
+            if (b.Lq <= 8) hipLaunchKernelGGL((k_knn_bvh_post_ring<DIM, false>), dim3(nb + ml->rp.n_red), dim3(BVH_THREADS), lds, c->stream, kf, bv, order, pp, ml->rp);
+            else hipLaunchKernelGGL((k_knn_bvh_post_ring<DIM, true>), dim3(nb + ml->rp.n_red), dim3(BVH_THREADS), lds, c->stream, kf, bv, order, pp, ml->rp);
+        }
+        else if (b.Lq <= 8) hipLaunchKernelGGL((k_knn_bvh_post<DIM, false>), dim3(nb), dim3(BVH_THREADS), lds, c->stream, kf, bv, order, pp);
         else hipLaunchKernelGGL((k_knn_bvh_post<DIM, true>), dim3(nb), dim3(BVH_THREADS), lds, c->stream, kf, bv, order, pp);
         *fused_blocks = nb;
     } else {
@@ -452,7 +463,7 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
 
 // Enqueue the matching stage (no sync).  fused_blocks != nullptr allows the BVH matcher to run the post stage as its epilogue;
 // it is set to the number of block partials written, or left 0 when the matcher in use does not fuse.
-int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr) {
+int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr, const MergeLaunch* ml = nullptr) {
     const icp_params& p = c->prm;
     int rc;
     if (fused_blocks) *fused_blocks = 0;
@@ -490,8 +501,8 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr) {
             kp.qstate = c->qstate.as<float4>(); kp.qstate2 = c->tier2 ? c->qstate2.as<float2>() : nullptr; kp.incremental = 1;
         }
         const Cloud* fuse = (fused_blocks != nullptr && p.metric != ICP_METRIC_SYMMETRIC && !q.pretransformed) ? q.cl : nullptr;
-        if (q.use_colors) return launch_bvh_query<6>(c, c->bvh6, target_coords6(c), kp, q.order, q.n, fuse, fused_blocks);
-        return launch_bvh_query<3>(c, c->bvh, target_coords3(c), kp, q.order, q.n, fuse, fused_blocks);
+        if (q.use_colors) return launch_bvh_query<6>(c, c->bvh6, target_coords6(c), kp, q.order, q.n, fuse, fused_blocks, fuse ? ml : nullptr);
+        return launch_bvh_query<3>(c, c->bvh, target_coords3(c), kp, q.order, q.n, fuse, fused_blocks, fuse ? ml : nullptr);
     }
     const int bx = (q.n + WAVE - 1) / WAVE;
     const int nch = kp.mpad / KNN_CH;
@@ -513,17 +524,25 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr) {
     return ICP_OK;
 }
 
+// The hand-over slots of k_reduce_solve (NSUM self-validating totals + the ticket) back to "nothing written": enqueued at the start of
+// every entry point that launches it, so that whatever an earlier call left behind -- a run cut short by a HIP error between a
+// block's publish and block 0's re-arm, a total that arrived after block 0 had given up -- can never be taken for a result.
+int rearm_handover(icp_ctx* c) {
+    int rc;
+    if ((rc = ensure(c, c->totals, NSUM * 8 + 8))) return rc;
+    HIPCK(c, hipMemsetAsync(c->totals.p, 0, NSUM * 8 + 8, c->stream));
+    if (c->spin_reduce) hipLaunchKernelGGL(k_fill_u64, dim3(1), dim3(64), 0, c->stream, c->totals.as<unsigned long long>(), NSUM, TOTAL_SENTINEL);
+    HIPCK(c, hipGetLastError());
+    return ICP_OK;
+}
+
 // Enqueue weight + reject + accumulate (+ symmetric second pass) + reduce/solve (no sync).
 int launch_post_and_solve(icp_ctx* c, const Cloud& src, const int* sel, int n, icp_iter_stats* d_stats, double* d_sums_out, int update_pose,
                           hipEvent_t ev_after_post, int fused_blocks = 0) {
     const icp_params& p = c->prm;
     int rc;
     if (!fused_blocks && (rc = ensure(c, c->partials, (size_t)POST_BLOCKS * NSUM * 8))) return rc;
-    if (!c->totals.p) {                                     // NSUM totals + the arrival counter of the reduce/solve kernel
-        if ((rc = ensure(c, c->totals, NSUM * 8 + 8))) return rc;
-        HIPCK(c, hipMemsetAsync(c->totals.p, 0, NSUM * 8 + 8, c->stream));
-        if (c->spin_reduce) hipLaunchKernelGGL(k_fill_u64, dim3(1), dim3(64), 0, c->stream, c->totals.as<unsigned long long>(), NSUM, TOTAL_SENTINEL);
-    }
+    if (!c->totals.p && (rc = rearm_handover(c))) return rc;      // (the entry points re-arm before their first launch; this covers a first use)
     const PostParams pp = make_post_params(c, src, sel, n);
     int nb = (n + POST_THREADS - 1) / POST_THREADS; if (nb > POST_BLOCKS) nb = POST_BLOCKS; if (nb < 1) nb = 1;
     if (fused_blocks) nb = fused_blocks;                    // the matcher already wrote the block partials
@@ -671,6 +690,7 @@ int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out) {
     { const char* e = getenv("ICP_HIP_FUSE_POST"); if (e && e[0] == '0') c->fuse_post = false; }
     { const char* e = getenv("ICP_HIP_SPIN_REDUCE"); if (e) c->spin_reduce = e[0] == '1'; }
     { const char* e = getenv("ICP_HIP_TIER2"); if (e && e[0] == '0') c->tier2 = false; }
+    { const char* e = getenv("ICP_HIP_MERGE"); if (e && e[0] == '0') c->merge_loop = false; }
     { const char* e = getenv("ICP_HIP_PRESORT"); if (e && e[0] == '0') c->presort = false; }
     { const char* e = getenv("ICP_HIP_BLOCK_LEVELS"); if (e && e[0] == '0') c->block_levels = false; }
     { const char* e = getenv("ICP_HIP_TRACE"); if (e && e[0] == '1') c->trace = true; }
@@ -700,7 +720,7 @@ int icp_ctx_destroy(icp_ctx* c) {
     for (Bvh* b : {&c->bvh6, &c->nrm_bvh}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
     release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) release(kv.second);
-    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->qstate2); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->totals); release(c->dbg_steps); release(c->sums);
+    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->qstate2); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->partials2); release(c->ring); release(c->totals); release(c->dbg_steps); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
     for (DevBuf* d : {&c->src_flag, &c->src_box, &c->tgt_flag, &c->tgt_finite, &c->nrm_finite, &c->sel_temp, &c->d_count}) release(*d);
     if (c->pin_up) (void)hipHostFree(c->pin_up);
@@ -818,13 +838,52 @@ int icp_correspond(icp_ctx* c, const float pose[16], icp_match_t* out, double* s
     QuerySet q{&c->src, nullptr, c->src.n, 0, c->prm.color_icp != 0 && c->prm.matching == ICP_MATCH_KNN, false, full_order};
     if ((rc = launch_match(c, q))) return rc;
     if ((rc = ensure(c, c->sums, NSUM * 8))) return rc;
+    if ((rc = rearm_handover(c))) return rc;
     if ((rc = launch_post_and_solve(c, c->src, nullptr, q.n, nullptr, c->sums.as<double>(), 0, nullptr))) return rc;
-    double hs[NSUM];
+    double hs[NSUM]; int fault = 0;
     if (out) HIPCK(c, hipMemcpyAsync(out, c->matches.p, (size_t)q.n * sizeof(icp_match_t), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(hs, c->sums.p, NSUM * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(&fault, &c->ps.as<PoseState>()->fault, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    if (fault) { c->err = "reduction hand-over timed out on the device (k_reduce_solve)"; return ICP_ERR_HIP; }
     if (sums_out) { memset(sums_out, 0, 64 * 8); memcpy(sums_out, hs, NSUM * 8); }
     if (n_valid_out) *n_valid_out = (int32_t)hs[SUM_N];
+    return guard.done();
+}
+
+// The fused matcher driven launch by launch with caller-dictated poses: launch 0 unseeded, launch j > 0 seeded + incremental exactly
+// as iteration j of run_loop (same kernel, same buffers, same launch parameters); the last launch's records come back in source order.
+int icp_match_seeded(icp_ctx* c, const float* poses, int32_t n_poses, icp_match_t* out, float* d2_out) {
+    if (!c || !poses || n_poses <= 0) { if (c) c->err = "icp_match_seeded: bad argument"; return ICP_ERR_INVALID_ARG; }
+    const icp_params& p = c->prm;
+    if (p.matching != ICP_MATCH_KNN || p.knn_backend != ICP_KNN_LBVH || p.metric == ICP_METRIC_SYMMETRIC || !c->fuse_post) {
+        c->err = "icp_match_seeded: needs k-NN matching on the LBVH backend with the fused point-to-point / point-to-plane matcher"; return ICP_ERR_INVALID_ARG;
+    }
+    int rc;
+    DrainOnError guard(c);
+    if ((rc = set_device(c))) return rc;
+    if ((rc = check_ready(c, true, true))) return rc;
+    const Cloud* cloud = nullptr; int n = 0;
+    if ((rc = get_sorted_level(c, 0, &cloud, &n))) return rc;
+    struct Keep { icp_ctx* c; ~Keep() { c->keep_fused_records = false; } } keep{c};
+    for (int j = 0; j < n_poses; j++) {
+        if ((rc = write_pose(c, poses + (size_t)16 * j))) return rc;
+        c->keep_fused_records = (j == n_poses - 1);
+        QuerySet q{cloud, nullptr, n, 0, p.color_icp != 0, j > 0, nullptr};
+        int fused = 0;
+        if ((rc = launch_match(c, q, &fused))) return rc;
+        if (!fused) { c->err = "icp_match_seeded: the matcher did not take the fused path"; return ICP_ERR_INVALID_ARG; }
+        HIPCK(c, hipStreamSynchronize(c->stream));           // the pose staging area is reused by the next launch
+    }
+    std::vector<int> pos((size_t)n); std::vector<icp_match_t> m((size_t)n); std::vector<float> d((size_t)n);
+    HIPCK(c, hipMemcpyAsync(pos.data(), c->levels[0].sorted_idx.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(m.data(), c->matches.p, (size_t)n * sizeof(icp_match_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(d.data(), c->d2.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    for (int t = 0; t < n; t++) {                            // sorted position -> source index
+        if (out) out[pos[(size_t)t]] = m[(size_t)t];
+        if (d2_out) d2_out[pos[(size_t)t]] = d[(size_t)t];
+    }
     return guard.done();
 }
 
@@ -872,7 +931,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     if (iters == 0) return guard.done();
     // page-locked staging for the whole run up front: [pose state up | per-iteration records down | pose state down]
     const size_t pin_stats = 256, pin_pose = pin_stats + (((size_t)iters * sizeof(icp_iter_stats) + 255) & ~(size_t)255);
-    if ((rc = ensure_pinned(c, pin_pose + 256))) return rc;
+    if ((rc = ensure_pinned(c, pin_pose + 512))) return rc;
     float pose_in[16]; memcpy(pose_in, pose_inout, 64);        // the record of an empty iteration 0 carries the incoming pose
     if ((rc = write_pose(c, pose_inout))) return rc;
     if ((rc = ensure(c, c->stats, (size_t)iters * sizeof(icp_iter_stats)))) return rc;
@@ -917,15 +976,48 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     const bool rmse = (p.record_rmse & 1) && c->conv_n > 0;
     const bool fontana = (p.record_rmse & 2) && c->conv_n > 0;
     if (rmse) { if ((rc = ensure(c, c->rmse_partials, 256 * 2 * 8))) return rc; }
+    // The merged loop (dev_solve.hpp, "the ring form"): point-to-plane through the fused BVH matcher on sorted levels, nothing else on
+    // the stream between two iterations.  Launch i = [reducer of iteration i - 1 | matcher of iteration i]; one reducer-only launch closes
+    // the run.  Pose slots and totals rows are written once per run; both rings are reset here, so nothing survives an aborted run.
+    bool merged = c->merge_loop && !single && iters >= 2 && sorted_levels && c->fuse_post && p.metric == ICP_METRIC_POINT_TO_PLANE && !rmse && !fontana && !ICP_DEBUG_CUT;
+    for (int i = 0; merged && i < iters; i++) if (ns[i] <= 0) merged = false;
+    PoseState* slots = nullptr; unsigned long long* trows = nullptr; int* run_fault = nullptr;
+    if (merged) {
+        static_assert(sizeof(PoseState) == 128, "a pose slot is 16 granules");
+        const size_t slot_bytes = (size_t)(iters + 1) * sizeof(PoseState), tot_bytes = (size_t)iters * NSUM * 8;
+        int nbmax = POST_BLOCKS;
+        for (int i = 0; i < iters; i++) { const int nb = (ns[i] + BVH_THREADS - 1) / BVH_THREADS; if (nb > nbmax) nbmax = nb; }
+        if ((rc = ensure(c, c->ring, slot_bytes + tot_bytes + 64))) return rc;
+        if ((rc = ensure(c, c->partials, (size_t)nbmax * NSUM * 8))) return rc;
+        if ((rc = ensure(c, c->partials2, (size_t)nbmax * NSUM * 8))) return rc;
+        slots = c->ring.as<PoseState>(); trows = (unsigned long long*)(c->ring.as<char>() + slot_bytes); run_fault = (int*)(c->ring.as<char>() + slot_bytes + tot_bytes);
+        HIPCK(c, hipMemsetAsync(c->ring.p, 0xFF, slot_bytes + tot_bytes, c->stream));
+        HIPCK(c, hipMemsetAsync(run_fault, 0, 64, c->stream));
+        HIPCK(c, hipMemcpyAsync(slots, c->ps.p, sizeof(PoseState), hipMemcpyDeviceToDevice, c->stream));      // slot 0 = the incoming pose (write_pose above)
+    }
     // Stage timing (TimeMeasure.h:20-26).  A HIP event costs ~4 us of stream time, two to three per iteration are ~10 % of a
     // 0.07 ms iteration: mode N > 1 brackets only every Nth iteration (offset rotating from run to run) and scales the sums.
-    // Event slots: 4 per iteration (start, after match, after post, end) + run start / run end.
+    // Event slots: 4 per iteration (start, after match, after post, end) + run start / run end.  In the merged loop an iteration is ONE
+    // launch (its reduce + solve happen inside the next one): "match" is that launch, "solve" only the closing reducer-only launch.
     const int tmode = c->stage_timing;
     std::vector<char> sampled((size_t)iters, 0), post_event((size_t)iters, 0);
     for (int i = 0; i < iters; i++) sampled[i] = tmode == 1 || (tmode > 1 && (i + (int)(c->timing_phase % (unsigned)tmode)) % tmode == 0);
     c->timing_phase++;
     auto E = [&](int i, int k) { return c->events[(size_t)2 + 4 * i + k]; };
-    auto start_event = [&](int i) { return (i > 0 && sampled[i - 1]) ? E(i - 1, 3) : E(i, 0); };
+    auto end_event = [&](int i) { return (merged && i < iters - 1) ? E(i, 1) : E(i, 3); };
+    auto start_event = [&](int i) { return (i > 0 && sampled[i - 1]) ? end_event(i - 1) : E(i, 0); };
+    auto ring_params = [&](int i) {                      // the reducer of iteration i - 1, riding in launch i (i = iters: the closing launch)
+        RingParams rp; memset(&rp, 0, sizeof(rp));
+        rp.run_fault = run_fault;
+        if (i > 0) {
+            rp.n_red = NSUM_USED;
+            rp.red_partials = ((i - 1) & 1) ? c->partials2.as<double>() : c->partials.as<double>(); rp.red_nblocks = (ns[i - 1] + BVH_THREADS - 1) / BVH_THREADS;
+            rp.totals_row = trows + (size_t)(i - 1) * NSUM; rp.ps_in = slots + (i - 1); rp.ps_out = slots + i;
+            rp.stats = c->stats.as<icp_iter_stats>() + (i - 1); rp.n_src = ns[i - 1];
+        }
+        return rp;
+    };
+    if (!merged && (rc = rearm_handover(c))) return rc;
     HIPCK(c, hipEventRecord(c->events[0], c->stream));
     for (int i = 0; i < iters; i++) {
         icp_iter_stats* d_st = c->stats.as<icp_iter_stats>() + i;
@@ -939,11 +1031,16 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
 #if ICP_DEBUG_CUT
             c->dbg_iter = i;
 #endif
-            if ((rc = launch_match(c, q, c->fuse_post ? &fused : nullptr))) return rc;
+            MergeLaunch ml;
+            if (merged) { ml.rp = ring_params(i); ml.slot = slots + i; ml.partials = (i & 1) ? c->partials2.as<double>() : c->partials.as<double>(); }
+            if ((rc = launch_match(c, q, c->fuse_post ? &fused : nullptr, merged ? &ml : nullptr))) return rc;
+            if (merged && !fused) { c->err = "merged loop: the matcher did not take the fused path"; return ICP_ERR_HIP; }
             if (ev) HIPCK(c, hipEventRecord(E(i, 1), c->stream));
             // fused epilogue: there is no separate post stage to bracket
-            if ((rc = launch_post_and_solve(c, *clouds[i], sels[i], ns[i], d_st, nullptr, 1, (ev && !fused) ? E(i, 2) : nullptr, fused))) return rc;
-            post_event[i] = ev && !fused;
+            if (!merged) {
+                if ((rc = launch_post_and_solve(c, *clouds[i], sels[i], ns[i], d_st, nullptr, 1, (ev && !fused) ? E(i, 2) : nullptr, fused))) return rc;
+                post_event[i] = ev && !fused;
+            }
         } else if (ev) {
             HIPCK(c, hipEventRecord(E(i, 1), c->stream));
         }
@@ -953,13 +1050,35 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
             hipLaunchKernelGGL(k_rmse_finish, dim3(1), dim3(64), 0, c->stream, c->rmse_partials.as<double>(), 256, &d_st->rmse);
         }
         if (fontana && (rc = enqueue_fontana(c, &d_st->benchmark_error))) return rc;
-        if (ev) HIPCK(c, hipEventRecord(E(i, 3), c->stream));
+        if (merged && i == iters - 1) {                  // the closing launch: reducer of the last iteration, nothing behind it
+            hipLaunchKernelGGL(k_ring_reduce_solve, dim3(NSUM_USED), dim3(RING_THREADS), 0, c->stream, ring_params(iters));
+            HIPCK(c, hipGetLastError());
+        }
+        if (ev && !(merged && i < iters - 1)) HIPCK(c, hipEventRecord(E(i, 3), c->stream));
     }
     HIPCK(c, hipEventRecord(c->events[1], c->stream));
     std::vector<icp_iter_stats> hs((size_t)iters);
+    const PoseState* d_final = merged ? slots + iters : c->ps.as<PoseState>();
     HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_stats, c->stats.p, (size_t)iters * sizeof(icp_iter_stats), hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_pose, c->ps.p, sizeof(PoseState), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_pose, d_final, sizeof(PoseState), hipMemcpyDeviceToHost, c->stream));
+    if (merged) HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_pose + 128, run_fault, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    if (merged) {
+        c->merged_runs++;
+        const PoseState* hp = (const PoseState*)((char*)c->pinned + pin_pose);
+        const int rf = *(const int*)((char*)c->pinned + pin_pose + 128);
+        if (hp->fault || rf) {
+            // a pivot of the 6 x 6 system failed the rank test (the eigen fallback lives in k_reduce_solve only), or a bounded wait ran out:
+            // the same run again, from the incoming pose, with the separate launches
+            c->merged_fallbacks++;
+            guard.ok = true;                                 // synchronised
+            memcpy(pose_inout, pose_in, 64);
+            c->merge_loop = false;
+            const int rc2 = run_loop(c, pose_inout, stats, max_stats, n_run, single);
+            c->merge_loop = true;
+            return rc2;
+        }
+    }
     memcpy(hs.data(), (char*)c->pinned + pin_stats, (size_t)iters * sizeof(icp_iter_stats));
     memcpy(pose_inout, ((const PoseState*)((char*)c->pinned + pin_pose))->pose, 64);
     if (((const PoseState*)((char*)c->pinned + pin_pose))->fault) { c->err = "reduction hand-over timed out on the device (k_reduce_solve)"; return ICP_ERR_HIP; }
@@ -981,7 +1100,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
         float a = 0, b = 0, d = 0;
         HIPCK(c, hipEventElapsedTime(&a, start_event(i), E(i, 1)));
         if (post_event[i]) HIPCK(c, hipEventElapsedTime(&b, E(i, 1), E(i, 2)));
-        HIPCK(c, hipEventElapsedTime(&d, post_event[i] ? E(i, 2) : E(i, 1), E(i, 3)));
+        if (!(merged && i < iters - 1)) HIPCK(c, hipEventElapsedTime(&d, post_event[i] ? E(i, 2) : E(i, 1), E(i, 3)));
         t.match_ms += a; t.weight_reject_build_ms += b; t.solve_ms += d;
         c->it_match_ms[(size_t)i] = a; c->it_post_ms[(size_t)i] = b; c->it_solve_ms[(size_t)i] = d;
         if (c->trace) fprintf(stderr, "[icp_hip] it %2d  n %d  match %.4f  post %.4f  solve %.4f ms\n", i, ns[i], a, b, d);
@@ -1179,6 +1298,27 @@ int icp_debug_steps(icp_ctx* c, int32_t* out, int32_t n) {
     int rc;
     if ((rc = set_device(c))) return rc;
     HIPCK(c, hipMemcpy(out, c->dbg_steps.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return ICP_OK;
+}
+
+// Development / test hooks (not part of icp_hip.h; called by tests/ through ctypes).
+//   icp_debug_counters        : how many runs of this context took the merged loop, and how many of those had to be repeated with the
+//                               separate k_reduce_solve launches (rank-deficient system, or a bounded wait that ran out).
+//   icp_debug_poison_handover : leaves a stale, valid-looking total in slot `slot` of k_reduce_solve's hand-over area -- what a run cut
+//                               short between a block's publish and block 0's re-arm would leave behind.  The next call must not see it.
+int icp_debug_counters(icp_ctx* c, int32_t* merged_runs, int32_t* merged_fallbacks) {
+    if (!c) return ICP_ERR_INVALID_ARG;
+    if (merged_runs) *merged_runs = c->merged_runs;
+    if (merged_fallbacks) *merged_fallbacks = c->merged_fallbacks;
+    return ICP_OK;
+}
+int icp_debug_poison_handover(icp_ctx* c, int32_t slot, double value) {
+    if (!c || slot < 0 || slot >= NSUM) return ICP_ERR_INVALID_ARG;
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    if (!c->totals.p && (rc = rearm_handover(c))) return rc;
+    HIPCK(c, hipMemcpyAsync(c->totals.as<double>() + slot, &value, 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
     return ICP_OK;
 }
 

@@ -57,7 +57,7 @@ COMM_ID_BYTES = 128
 
 # every symbol include/icp_hip.h declares (tests check the library exports all of them)
 EXPORTS = ["icp_ctx_create", "icp_ctx_create_on_stream", "icp_ctx_destroy", "icp_last_error", "icp_params_default",
-           "icp_set_params", "icp_get_params", "icp_set_target", "icp_set_source", "icp_query_matches", "icp_match",
+           "icp_set_params", "icp_get_params", "icp_set_target", "icp_set_source", "icp_query_matches", "icp_match", "icp_match_seeded",
            "icp_correspond", "icp_iterate", "icp_run", "icp_get_timing", "icp_get_iteration_times", "icp_set_stage_timing", "icp_set_convergence_reference", "icp_rmse", "icp_benchmark_error",
            "icp_transform_points", "icp_transform_normals", "icp_version", "icp_schedule", "icp_select_hash", "icp_backproject_depth", "icp_estimate_normals",
            "icp_batch_run", "icp_pair_owner", "icp_pairs_of_rank", "icp_comm_unique_id", "icp_comm_create", "icp_comm_destroy", "icp_gather_poses",
@@ -170,6 +170,14 @@ class Context:
     def match(self, pose):
         out = np.empty(self.n_src, MATCH_DTYPE); d2 = np.empty(self.n_src, np.float32)
         self._ck(self.lib.icp_match(self.h, _ptr(pose_to_c(pose)), _ptr(out), _ptr(d2)))
+        return out, d2
+
+    def match_seeded(self, poses):
+        """icp_match_seeded: the fused matcher launched once per pose (first unseeded, then seeded + incremental as in the loop);
+        returns the last launch's (Match records after weighting / rejection, squared distances) in source order."""
+        ps = np.ascontiguousarray(np.stack([pose_to_c(p) for p in poses]), dtype=np.float32)
+        out = np.empty(self.n_src, MATCH_DTYPE); d2 = np.empty(self.n_src, np.float32)
+        self._ck(self.lib.icp_match_seeded(self.h, _ptr(ps), C.c_int32(len(ps)), _ptr(out), _ptr(d2)))
         return out, d2
 
     def correspond(self, pose):

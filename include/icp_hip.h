@@ -127,6 +127,15 @@ int icp_query_matches(icp_ctx* ctx, const float* transformed_xyz, const uint8_t*
  *                  validity filter (ICPOptimizer.h:594-610).  sums_out (optional, 64 doubles) receives the
  *                  reduced accumulators the solver consumes (layout in DESIGN.md), n_valid_out the count. */
 int icp_match(icp_ctx* ctx, const float pose[16], icp_match_t* out, float* d2_out);
+/* The search exactly as the loop of icp_run runs it (parity-test entry point for the seeded / incremental path, NearestNeighbor.h:81-97
+ * semantics): the fused matcher of the k-NN BVH backend is launched once per pose of poses[0 .. n_poses) (column-major, 16 floats
+ * each) on the Morton-sorted resident source -- the first launch unseeded, every further one seeded with the previous launch's
+ * neighbours and search state (verify-and-skip tiers, shared walks, spread start: whatever knn_incremental and the build enable),
+ * i.e. launch j is iteration j of a run whose poses are dictated by the caller.  out / d2_out (optional) receive the LAST launch's
+ * records in source order: the Match after weighting + rejection (= what icp_correspond returns; with rejection 0 and constant
+ * weights the raw {idx, 1} / {-1, 0} of queryMatches) and the winning squared distance (FLT_MAX when there was no candidate).
+ * Needs matching = k-NN, knn_backend = LBVH, a metric other than symmetric, normals on both clouds; ICP_ERR_INVALID_ARG otherwise. */
+int icp_match_seeded(icp_ctx* ctx, const float* poses, int32_t n_poses, icp_match_t* out, float* d2_out);
 int icp_correspond(icp_ctx* ctx, const float pose[16], icp_match_t* out, double* sums_out, int32_t* n_valid_out);
 
 /* -------- one iteration / the whole loop: LinearICPOptimizer::estimatePose, ICPOptimizer.h:493-663 --------

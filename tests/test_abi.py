@@ -74,3 +74,27 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(base, f), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "libicp_oracle" not in txt, f
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """A host without librccl: icp_comm_unique_id / icp_comm_create return ICP_ERR_COMM with a message (the header promises a single-GPU
+    host needs no RCCL at all).  Forced here through ICP_HIP_RCCL_LIB, in a child process (the library caches what it loaded)."""
+    import sys
+    code = (
+        "import ctypes, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from icp_amd import binding\n"
+        "lib = binding.load_library()\n"
+        "buf = (ctypes.c_uint8 * 128)()\n"
+        "rc = lib.icp_comm_unique_id(buf)\n"
+        "msg = lib.icp_comm_last_error().decode()\n"
+        "h = ctypes.c_void_p()\n"
+        "rc2 = lib.icp_comm_create(0, 1, 0, buf, ctypes.byref(h))\n"
+        "print(rc, rc2, msg)\n" % os.path.join(ROOT, "icp-variants_amd", "python"))
+    env = dict(os.environ, ICP_HIP_RCCL_LIB="/nonexistent/librccl.so.1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rc, rc2, msg = out.stdout.strip().split(" ", 2)
+    assert int(rc) == 10                                    # ICP_ERR_COMM
+    assert int(rc2) in (9, 10)                              # no HIP device on a CPU box (ICP_ERR_NO_DEVICE), ICP_ERR_COMM on a GPU box
+    assert "ICP_HIP_RCCL_LIB" in msg and "/nonexistent/librccl.so.1" in msg
