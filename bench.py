@@ -461,6 +461,12 @@ def main():
         "pose_error_vs_gt": {"rot_rad": rot_err, "trans_m": trans_err},
         "pose_gather": gather.kind,
     }
+    import ctypes as _C
+    _a, _b = _C.c_int32(0), _C.c_int32(0)
+    if ctx.lib.icp_debug_counters(ctx.h, _C.byref(_a), _C.byref(_b)) == 0:
+        out["loop_form"] = {"runs_in_one_launch_per_level_or_merged_form": _a.value, "of_those_repeated_with_separate_launches": _b.value,
+                            "note": "icp_run keeps the whole loop of a resolution level in ONE launch (k_icp_loop) when its grid fits the device, else rides the reducer "
+                                    "in front of the next matcher launch; a run whose 6x6 system needs the eigen fallback is repeated with separate k_reduce_solve launches"}
     if gather.error:
         out["pose_gather_error"] = gather.error
     if args.knn == "brute":

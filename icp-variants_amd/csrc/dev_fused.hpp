@@ -33,107 +33,98 @@ struct P2pGen {                                           // values 0..21 = sum 
 // query, a stable 8-class rank in the epilogue): iterations 1-9 0.084 vs 0.079 ms -- the prediction is not worth the extra dependent
 // load in front of everything and the gathers.  What did pay was making k_reduce_solve itself cheaper (one load
 // round, fence-free hand-over): see dev_solve.hpp.
-#ifndef ICP_DEBUG_CUT
-#define ICP_DEBUG_CUT 0          // 1: development build, kp.nseg = 100 + c ends ONE chosen launch early at cut point c (its results are garbage; its duration is the point)
-#endif
-#if ICP_DEBUG_CUT
-#define ICP_CUT(c) do { if (kp.nseg == 100 + (c)) return; } while (0)
-#else
-#define ICP_CUT(c)
-#endif
 #ifndef ICP_DEBUG_TIMES
 #define ICP_DEBUG_TIMES 0        // 1 (with ICP_DEBUG_STEPS=1 for the buffer): lane 0 of every wave leaves 100 MHz timestamps of its phases in dbg_steps[8 * wave ..]
 #endif
 #if ICP_DEBUG_TIMES
-#define ICP_STAMP(j) do { if (kp.dbg_steps && lane == 0) kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + (j)] = (int)(unsigned int)wall_clock64(); } while (0)
+#define ICP_STAMP(j) do { if (kp.dbg_steps && lane == 0) kp.dbg_steps[8 * (wave_slot) + (j)] = (int)(unsigned int)wall_clock64(); } while (0)
 #else
 #define ICP_STAMP(j)
 #endif
-// MERGED: the launch of iteration i carries the reducer of iteration i - 1 in its first rp.n_red blocks and every matcher block waits
-// for the pose they publish (dev_solve.hpp, "the ring form") -- AFTER it has issued the loads that do not need the pose.
-template <int DIM, bool WIDE, bool MERGED>      // WIDE: trees deeper than 8 levels of 4-wide nodes (> 524 288 targets) keep 64 pending bits per lane
-__device__ __forceinline__ void fused_matcher_body(const KnnParams& kp, const BvhViewT<DIM>& bv, const int* __restrict__ qorder, const PostParams& pp, const RingParams& rp) {
-    extern __shared__ uint2 bvh_lbq[];                    // [ICP_SHARE_ROWS][BVH_THREADS]: the shared walk's records; reused by the reduction
-    constexpr int NW = BVH_THREADS / WAVE;
-    if constexpr (MERGED) { if ((int)blockIdx.x < rp.n_red) { ring_reduce_solve(rp); return; } }
-    const int n_red = MERGED ? rp.n_red : 0;
-    const int mblock = (int)blockIdx.x - n_red, mgrid = (int)gridDim.x - n_red;      // this block / the grid among the matcher blocks
-    // Pose and normal matrix through the constant address space: wave-uniform and unchanged for the length of the launch (k_reduce_solve
-    // wrote them before it), so they can be SCALAR loads, issued here with the arguments, instead of per-lane vector loads that the
-    // compiler places behind the wait for the query's own loads (one more dependent trip in front of every launch) and keeps in 21 VGPRs.
-    // (MERGED: they arrive through ring_wait_pose below, into scalar registers as well.)
-    typedef const __attribute__((address_space(4))) float* cfloat_p;
-    float Pm[16], Nm[9];
-    if constexpr (!MERGED) {
-        const cfloat_p pc = (cfloat_p)(const void*)kp.ps->pose; const cfloat_p nc = (cfloat_p)(const void*)kp.ps->nmat;
+
+// What a query brings along that does not depend on the pose: requested in ONE batch (point, normal, previous neighbour, search
+// state), then the neighbour's record -- two memory round trips before the verify test instead of one per array; in the late
+// iterations, where almost no query walks, those round trips ARE the per-launch kernels.  The persistent loop (dev_persist.hpp) keeps
+// all of it in registers from one iteration to the next for as long as the wave's queries verify.
+template <int DIM> struct QueryIn {
+    float r0, r1, r2;            // source point (untransformed)
+    float c3, c4, c5;            // colour features (DIM == 6)
+    float rn0, rn1, rn2;         // source normal
+    int q0;                      // position (8 * leaf + slot) of the previous neighbour; -1: none
+    float4 st;                   // anchor of the last search + lower bound on the distance from it to every other target
+    float4 ra, rb;               // the previous neighbour's 32-byte record (DIM == 3: its coordinates too)
+    float tq[DIM]; int j0;       // the previous neighbour's coordinates and original index
+};
+template <int DIM>
+__device__ __forceinline__ void fused_front_clear(QueryIn<DIM>& in) {
+    in.r0 = 0.f; in.r1 = 0.f; in.r2 = 0.f; in.c3 = 0.f; in.c4 = 0.f; in.c5 = 0.f; in.rn0 = 0.f; in.rn1 = 0.f; in.rn2 = 0.f; in.q0 = -1; in.j0 = -1;
+    in.st.x = 0.f; in.st.y = 0.f; in.st.z = 0.f; in.st.w = 0.f; in.ra = in.st; in.rb = in.st;
 #pragma unroll
-        for (int q = 0; q < 16; q++) Pm[q] = pc[q];
+    for (int q = 0; q < DIM; q++) in.tq[q] = 0.f;
+}
+template <int DIM>
+__device__ __forceinline__ void fused_front_loads(const KnnParams& kp, const PostParams& pp, const BvhViewT<DIM>& bv, int k, bool seeded, bool inc, QueryIn<DIM>& in) {
+    fused_front_clear<DIM>(in);
+    if (k >= 0) {
+        const int i = kp.sel ? kp.sel[k] : k;
+        in.r0 = kp.sx[i]; in.r1 = kp.sy[i]; in.r2 = kp.sz[i];
+        if (DIM == 6) { in.c3 = kp.scr[i]; in.c4 = kp.scg[i]; in.c5 = kp.scb[i]; }
+        in.rn0 = pp.snx[i]; in.rn1 = pp.sny[i]; in.rn2 = pp.snz[i];
+        in.q0 = seeded ? kp.nn_raw[k] : -1;
+        if (inc) in.st = kp.qstate[k];                     // (the second tier's 8 bytes are fetched only by the queries the first tier does not verify)
+        if (in.q0 >= 0) {
+            if (DIM == 3) { in.ra = *(const float4*)(bv.recs + in.q0); in.rb = *((const float4*)(bv.recs + in.q0) + 1); in.tq[0] = in.ra.x; in.tq[1] = in.ra.y; in.tq[2] = in.ra.z; in.j0 = __float_as_int(in.ra.w); }
+            else {
+                const BvhLeafT<DIM>* lf = bv.leaves + (in.q0 >> 3);
 #pragma unroll
-        for (int q = 0; q < 9; q++) Nm[q] = nc[q];
+                for (int q = 0; q < DIM; q++) in.tq[q] = lf->c[q][in.q0 & 7];
+                in.j0 = lf->idx[in.q0 & 7];
+            }
+        }
     }
-    ICP_CUT(1);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int t0 = xcd_contiguous_block(mblock, mgrid) * BVH_THREADS;
-    const int t = t0 + tid;
-    ICP_STAMP(0);
-    const int k = (t < kp.n) ? (qorder ? qorder[t] : t) : -1;
-    bool valid = false;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, d0 = 0.f, d1 = 0.f, d2 = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, wt = 0.f;
+}
+
+// One correspondence, as the epilogue consumes it.
+struct PairOut { bool valid; float s0, s1, s2, d0, d1, d2, n0, n1, n2, wt; };
+
+// Transform, verify (both tiers), search what does not verify (walks shared over the wave), weigh / reject: everything of one
+// iteration between "the pose is known" and "the lane holds its pair".  `searched` = this lane's query walked or took the two-leaf tier
+// (its search state was rewritten).  renewed (the persistent loop, DIM == 3): set for a lane whose query took the two-leaf tier in a wave that
+// did not walk -- `in` then holds its NEW state (anchor, bound, neighbour's record), ready to be parked again; a lane whose new state
+// cannot be given that way (no record fetched: the neighbour is past the distance threshold) leaves `searched` set instead.
+template <int DIM, bool WIDE>
+__device__ __forceinline__ void fused_search_post(const KnnParams& kp, const BvhViewT<DIM>& bv, const PostParams& pp, int k, bool seeded, bool inc, const float* Pm, const float* Nm,
+                                                  QueryIn<DIM>& in, uint2* __restrict__ bvh_lbq, int tid, int wave_slot, PairOut& o, bool& searched, bool* renewed = nullptr) {
+    const int lane = tid & 63; (void)lane; (void)wave_slot; (void)seeded;
+    o.valid = false; o.s0 = 0.f; o.s1 = 0.f; o.s2 = 0.f; o.d0 = 0.f; o.d1 = 0.f; o.d2 = 0.f; o.n0 = 0.f; o.n1 = 0.f; o.n2 = 0.f; o.wt = 0.f;
     float p[DIM];
 #pragma unroll
     for (int q = 0; q < DIM; q++) p[q] = 0.f;
-    float rn0 = 0.f, rn1 = 0.f, rn2 = 0.f;
-    float best = FLT_MAX, lb_others = 0.f; int bi = -1, bpos = -1, q0 = -1;
-    float4 ra, rb; ra.x = 0.f; ra.y = 0.f; ra.z = 0.f; ra.w = 0.f; rb = ra;
+    if (DIM == 6) { p[3 % DIM] = in.c3; p[4 % DIM] = in.c4; p[5 % DIM] = in.c5; }
+    float rn0 = in.rn0, rn1 = in.rn1, rn2 = in.rn2;
+    float best = FLT_MAX, lb_others = 0.f; int bi = -1, bpos = -1, q0 = in.q0;
+    float4 ra = in.ra, rb = in.rb;
 #if ICP_DEBUG_TIMES
     float dbg_lbo = 0.f, dbg_lb3 = 0.f, dbg_delta = 0.f;
 #endif
     bool need_walk = false, verified = false, two_leaf = false;
     float lb3 = 0.f; int l2 = -1;                         // second verification tier: bound on every target outside the neighbour's leaf and the runner-up's leaf l2
-    // ---- front end.  Everything that depends only on the query index is requested in ONE batch (point, normal, previous
-    // neighbour, search state), then the neighbour's record: two memory round trips before the verify test instead of
-    // one per array -- in the late iterations, where almost no query walks, those round trips ARE the kernel.  None of it needs the
-    // pose: in the merged loop all of it is in flight while the reducer blocks in front of this grid fold and solve.
-    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-    float4 st; st.x = 0.f; st.y = 0.f; st.z = 0.f; st.w = 0.f;
-    float tq[DIM]; int j0 = -1;
-#pragma unroll
-    for (int q = 0; q < DIM; q++) tq[q] = 0.f;
-    const bool seeded = kp.use_prev != 0, inc = kp.incremental && seeded;
-    if (k >= 0) {
-        const int i = kp.sel ? kp.sel[k] : k;
-        r0 = kp.sx[i]; r1 = kp.sy[i]; r2 = kp.sz[i];
-        if (DIM == 6) { p[3 % DIM] = kp.scr[i]; p[4 % DIM] = kp.scg[i]; p[5 % DIM] = kp.scb[i]; }
-        rn0 = pp.snx[i]; rn1 = pp.sny[i]; rn2 = pp.snz[i];
-        q0 = seeded ? kp.nn_raw[k] : -1;
-        if (inc) st = kp.qstate[k];                        // (the second tier's 8 bytes are fetched only by the queries the first tier does not verify)
-        if (q0 >= 0) {
-            if (DIM == 3) { ra = *(const float4*)(bv.recs + q0); rb = *((const float4*)(bv.recs + q0) + 1); tq[0] = ra.x; tq[1] = ra.y; tq[2] = ra.z; j0 = __float_as_int(ra.w); }
-            else {
-                const BvhLeafT<DIM>* lf = bv.leaves + (q0 >> 3);
-#pragma unroll
-                for (int q = 0; q < DIM; q++) tq[q] = lf->c[q][q0 & 7];
-                j0 = lf->idx[q0 & 7];
-            }
-        }
-    }
-    if constexpr (MERGED) { if (!ring_wait_pose(kp.ps, lane, rp.run_fault, Pm, Nm)) return; }
     if (k >= 0) {
         float2 st2; st2.x = 0.f; st2.y = __int_as_float(-1);
-        xform_point(Pm, r0, r1, r2, p[0], p[1], p[2]);
+        xform_point(Pm, in.r0, in.r1, in.r2, p[0], p[1], p[2]);
         if (finite3(p[0], p[1], p[2]) && bv.n_valid > 0) {
             need_walk = true;
             if (q0 >= 0) {                                 // seed_from_previous + knn_try_verify, on the batched loads
                 float d = 0.f;
 #pragma unroll
-                for (int q = 0; q < DIM; q++) { const float e = p[q] - tq[q]; d = (q == 0) ? e * e : d + e * e; }
-                if (d < best) { best = d; bi = j0; bpos = q0; }
+                for (int q = 0; q < DIM; q++) { const float e = p[q] - in.tq[q]; d = (q == 0) ? e * e : d + e * e; }
+                if (d < best) { best = d; bi = in.j0; bpos = q0; }
                 if (inc && bi >= 0) {
-                    const float ex = p[0] - st.x, ey = p[1] - st.y, ez = p[2] - st.z;
+                    const float ex = p[0] - in.st.x, ey = p[1] - in.st.y, ez = p[2] - in.st.z;
                     const float delta = sqrt_up((ex * ex + ey * ey) + ez * ez), sbest = sqrt_up(best);
-                    const float lbn = (st.w - delta) * 0.999999f;
+                    const float lbn = (in.st.w - delta) * 0.999999f;
 #if ICP_DEBUG_TIMES
-                    dbg_lbo = st.w; dbg_lb3 = st2.x; dbg_delta = delta;
+                    dbg_lbo = in.st.w; dbg_lb3 = st2.x; dbg_delta = delta;
 #endif
                     if (sbest < lbn) { lb_others = lbn; need_walk = false; verified = true; }
                     else {
@@ -150,20 +141,18 @@ __device__ __forceinline__ void fused_matcher_body(const KnnParams& kp, const Bv
         }
     }
     ICP_STAMP(1);
+    searched = need_walk || two_leaf;
+    if (renewed) *renewed = false;
 #if ICP_DEBUG_TIMES
-    if (kp.dbg_steps && k >= 0 && (need_walk || two_leaf) && kp.use_prev) {      // who is it that still searches?  (slot by query index; the clock tells the launch)
-        int* r = kp.dbg_steps + 8 * (mgrid * NW) + 8 * (k & 4095);
+    if (kp.dbg_steps && k >= 0 && (need_walk || two_leaf) && seeded) {      // who is it that still searches?  (slot by query index; the clock tells the launch)
+        int* r = kp.dbg_steps + 8 * kp.dbg_waves + 8 * (k & 4095);
         r[0] = k; r[1] = __float_as_int(best); r[2] = __float_as_int(dbg_lbo); r[3] = __float_as_int(dbg_lb3); r[4] = __float_as_int(dbg_delta); r[5] = two_leaf ? l2 : -2; r[6] = q0; r[7] = (int)(unsigned int)wall_clock64();
     }
-#endif
-#if ICP_DEBUG_TIMES
-    if (kp.dbg_steps) { const int nw_ = __popcll(__ballot(need_walk && !two_leaf)), nl_ = __popcll(__ballot(two_leaf)); if (lane == 0) { kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + 6] = nw_ | (nl_ << 8);
+    if (kp.dbg_steps) { const int nw_ = __popcll(__ballot(need_walk && !two_leaf)), nl_ = __popcll(__ballot(two_leaf)); if (lane == 0) { kp.dbg_steps[8 * wave_slot + 6] = nw_ | (nl_ << 8);
             // where the wave runs: HW_ID (id 4: simd [5:4], cu [11:8], sh [12], se [15:13]) and XCC_ID (id 20) -> bits 16.. of the second word
-            kp.dbg_steps[8 * ((t0 / BVH_THREADS) * NW + w) + 7] = (int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu) | (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16)); } }
+            kp.dbg_steps[8 * wave_slot + 7] = (int)((__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFFu) | (__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16)); } }
 #endif
-#if ICP_DEBUG_CUT
-    if (kp.nseg == 102) { if (k >= 0 && best == 123.f && lb_others == 77.f) pp.partials[0] = rn0 + rn1 + rn2 + lb3; return; }
-#endif
+    const bool took_two_leaf = two_leaf;
     if (two_leaf) {
         f2 p2[DIM];
 #pragma unroll
@@ -184,20 +173,22 @@ __device__ __forceinline__ void fused_matcher_body(const KnnParams& kp, const Bv
 #if ICP_DEBUG_STEPS && !ICP_DEBUG_TIMES
     if (k >= 0 && kp.dbg_steps) kp.dbg_steps[k] = need_walk ? -1 : two_leaf ? -2 : 0;      // -1: walk (overwritten with its length); -2: second tier, two leaves
 #endif
+    bool walked = false;                                  // wave-uniform: this wave's lanes searched (or helped): their neighbours' records are read again
 #if ICP_SHARE_WALKS
     if (__any(need_walk)) {
+        walked = true;
         float rn[3] = {rn0, rn1, rn2};
         knn_walk_shared<DIM, BVH_THREADS, typename std::conditional<WIDE, unsigned long long, unsigned int>::type>(bv, p, rn, need_walk, best, bi, bpos, lb_others, lb3, l2, bvh_lbq, tid);
         rn0 = rn[0]; rn1 = rn[1]; rn2 = rn[2];
         q0 = -2;                                          // the neighbour's record is read again below: it need not stay in registers while this lane helps
+        // (the persistent loop: a wave that walked reloads its queries' data in the next iteration -- said here in a way the register
+        //  allocator can see, so that none of it stays alive across the walk)
+        fused_front_clear<DIM>(in);
     }
 #else
     if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lb3, l2, bvh_lbq, tid, (ICP_DEBUG_STEPS && kp.dbg_steps) ? kp.dbg_steps + k : nullptr);
 #endif
     ICP_STAMP(2);
-#if ICP_DEBUG_CUT
-    if (kp.nseg == 103) { if (k >= 0 && best == 123.f && lb_others == 77.f) pp.partials[0] = rn0 + rn1 + rn2 + lb3 + ra.x + rb.x; return; }
-#endif
     if (k >= 0) {
         // A verified query keeps its stored anchor (position of the last full search) and bound: the triangle test stays valid
         // against the OLD anchor -- and is tighter than re-anchoring, (L - d1) - d2 <= L - |d1 + d2| -- and its neighbour is
@@ -209,45 +200,51 @@ __device__ __forceinline__ void fused_matcher_body(const KnnParams& kp, const Bv
         if (best <= kp.max_dist) { m.idx = bi; m.weight = 1.f; } else { m.idx = -1; m.weight = 0.f; }
         if (m.idx < 0) { if (pp.matches) pp.matches[k] = m; }
         else {
-            if (DIM != 3 || bpos != q0) { ra = *(const float4*)(bv.recs + bpos); rb = *((const float4*)(bv.recs + bpos) + 1); }      // one 32-byte record
-            d0 = ra.x; d1 = ra.y; d2 = ra.z; n0 = rb.x; n1 = rb.y; n2 = rb.z;
-            s0 = p[0]; s1 = p[1]; s2 = p[2];
-            valid = post_eval<true>(pp, k, m, d0, d1, d2, n0, n1, n2, __float_as_uint(rb.w), s0, s1, s2, wt, rn0, rn1, rn2, Nm);
+            if (walked || DIM != 3 || bpos != q0) { ra = *(const float4*)(bv.recs + bpos); rb = *((const float4*)(bv.recs + bpos) + 1); }      // one 32-byte record
+            o.d0 = ra.x; o.d1 = ra.y; o.d2 = ra.z; o.n0 = rb.x; o.n1 = rb.y; o.n2 = rb.z;
+            o.s0 = p[0]; o.s1 = p[1]; o.s2 = p[2];
+            o.valid = post_eval<true>(pp, k, m, o.d0, o.d1, o.d2, o.n0, o.n1, o.n2, __float_as_uint(rb.w), o.s0, o.s1, o.s2, o.wt, rn0, rn1, rn2, Nm);
+        }
+        if (DIM == 3 && renewed && took_two_leaf && !walked && (m.idx >= 0 || bpos == q0)) {
+            // the two-leaf tier re-anchored this query (knn_store_state above wrote the same to memory): hand the new state back
+            in.st.x = p[0]; in.st.y = p[1]; in.st.z = p[2]; in.st.w = lb_others; in.q0 = bpos; in.ra = ra; in.rb = rb;
+            in.tq[0] = ra.x; in.tq[1] = ra.y; in.tq[2] = ra.z; in.j0 = __float_as_int(ra.w);
+            *renewed = true; searched = false;
         }
     }
     ICP_STAMP(3);
-#if ICP_DEBUG_CUT
-    if (kp.nseg == 104) { if (valid && s0 == 123.f && wt == 77.f) pp.partials[0] = s1 + s2 + d0 + d1 + d2 + n0 + n1 + n2; return; }
-#endif
+}
+
+// ---- epilogue: the block's sums.  Every lane has at most one pair; its <= 27 contributions are folded over the wave with the
+// transposing reduction (wave_transpose_reduce_gen: permlane swaps + DPP, no LDS traffic), the two wave totals meet in LDS, and
+// threads 0..33 hand the block partial `tid` to store(tid, value) in the fixed slot order the reducer expects.  Both barriers of the
+// block are in here: the first one retires the traversal's use of the LDS rows.
+template <class StoreFn>
+__device__ __forceinline__ void fused_block_epilogue(const KnnParams& kp, const PostParams& pp, PairOut& o, uint2* __restrict__ bvh_lbq, int tid, int wave_slot, const StoreFn& store) {
+    constexpr int NW = BVH_THREADS / WAVE;
+    const int lane = tid & 63, w = tid >> 6; (void)wave_slot; (void)kp;
     __syncthreads();                                      // the traversal stacks are dead: reuse LDS for the reduction
-    // ---- epilogue: the block's sums.  Every lane has at most one pair; its <= 27 contributions are folded over the wave with
-    // the transposing reduction (wave_transpose_reduce_from: permlane swaps + DPP, no LDS traffic), the two wave totals meet in
-    // LDS, and threads 0..33 write the block partial in the fixed slot order the reducer expects.
     double* lds = (double*)bvh_lbq;                       // [NW][32] wave totals, then [NW] counts
     double tot;
     // a lane without a valid pair contributes zeros: its INPUTS are zeroed (10 selects) rather than each of its 27 contributions (54)
-    if (!valid) { s0 = 0.f; s1 = 0.f; s2 = 0.f; d0 = 0.f; d1 = 0.f; d2 = 0.f; n0 = 0.f; n1 = 0.f; n2 = 0.f; wt = 0.f; }
+    if (!o.valid) { o.s0 = 0.f; o.s1 = 0.f; o.s2 = 0.f; o.d0 = 0.f; o.d1 = 0.f; o.d2 = 0.f; o.n0 = 0.f; o.n1 = 0.f; o.n2 = 0.f; o.wt = 0.f; }
     if (pp.metric == ICP_METRIC_POINT_TO_PLANE) {
         RowTerms R;
-        build_rows(0, s0, s1, s2, d0, d1, d2, n0, n1, n2, wt, R);
+        build_rows(0, o.s0, o.s1, o.s2, o.d0, o.d1, o.d2, o.n0, o.n1, o.n2, o.wt, R);
         const RowSlotGen g{R};                            // 27 slots of [J^T J | J^T r]
         tot = wave_transpose_reduce_gen<6, 0>(g, lane);
     } else {                                              // point-to-point moments (see post_core): sum s, sum d, then the 16 weighted ones
-        const P2pGen g{{s0, s1, s2}, {d0, d1, d2}, (double)wt};
+        const P2pGen g{{o.s0, o.s1, o.s2}, {o.d0, o.d1, o.d2}, (double)o.wt};
         tot = wave_transpose_reduce_gen<6, 0>(g, lane);
     }
     ICP_STAMP(4);
-#if ICP_DEBUG_CUT
-    if (kp.nseg == 105) { if (tot == 123.0) pp.partials[0] = tot; return; }
-#endif
     {
-        const unsigned long long vm = __ballot(valid);    // the count is an integer: one ballot per wave
+        const unsigned long long vm = __ballot(o.valid);  // the count is an integer: one ballot per wave
         const int v = wave_value_of_lane(lane);
         if (v < 32) lds[w * 32 + v] = tot;                // values past the last one are exact zeros
         if (lane == 0) lds[NW * 32 + w] = (double)__popcll(vm);
     }
     __syncthreads();
-    const int nb = mgrid, lb = t0 / BVH_THREADS;                                  // partial slot = logical block -> fixed summation order
     if (tid < NSUM_USED) {                                // threads 0..33: this block's sum `tid`
         double out = 0.0;
         if (tid == SUM_N) { for (int ww = 0; ww < NW; ww++) out += lds[NW * 32 + ww]; }
@@ -258,9 +255,48 @@ __device__ __forceinline__ void fused_matcher_body(const KnnParams& kp, const Bv
             const int nv = pp.metric == ICP_METRIC_POINT_TO_PLANE ? 27 : 22;
             if (v >= 0 && v < nv) { for (int ww = 0; ww < NW; ww++) out += lds[ww * 32 + v]; }
         }
-        pp.partials[(size_t)tid * nb + lb] = out;
+        store(tid, out);
     }
     ICP_STAMP(5);
+}
+
+// One launch per iteration.  MERGED: the launch of iteration i carries the reducer of iteration i - 1 in its first rp.n_red blocks and
+// every matcher block waits for the pose they publish (dev_solve.hpp, "the ring form") -- AFTER it has issued the loads that do not
+// need the pose.
+template <int DIM, bool WIDE, bool MERGED>      // WIDE: trees deeper than 8 levels of 4-wide nodes (> 524 288 targets) keep 64 pending bits per lane
+__device__ __forceinline__ void fused_matcher_body(const KnnParams& kp, const BvhViewT<DIM>& bv, const int* __restrict__ qorder, const PostParams& pp, const RingParams& rp) {
+    extern __shared__ uint2 bvh_lbq[];                    // [ICP_SHARE_ROWS][BVH_THREADS]: the shared walk's records; reused by the reduction
+    constexpr int NW = BVH_THREADS / WAVE;
+    if constexpr (MERGED) { if ((int)blockIdx.x < rp.n_red) { ring_reduce_solve(rp); return; } }
+    const int n_red = MERGED ? rp.n_red : 0;
+    const int mblock = (int)blockIdx.x - n_red, mgrid = (int)gridDim.x - n_red;      // this block / the grid among the matcher blocks
+    // Pose and normal matrix through the constant address space: wave-uniform and unchanged for the length of the launch (k_reduce_solve
+    // wrote them before it), so they can be SCALAR loads, issued here with the arguments, instead of per-lane vector loads that the
+    // compiler places behind the wait for the query's own loads (one more dependent trip in front of every launch) and keeps in 21 VGPRs.
+    // (MERGED: they arrive through ring_wait_pose below, into scalar registers as well.)
+    typedef const __attribute__((address_space(4))) float* cfloat_p;
+    float Pm[16], Nm[9];
+    if constexpr (!MERGED) {
+        const cfloat_p pc = (cfloat_p)(const void*)kp.ps->pose; const cfloat_p nc = (cfloat_p)(const void*)kp.ps->nmat;
+#pragma unroll
+        for (int q = 0; q < 16; q++) Pm[q] = pc[q];
+#pragma unroll
+        for (int q = 0; q < 9; q++) Nm[q] = nc[q];
+    }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lb = xcd_contiguous_block(mblock, mgrid);                              // partial slot = logical block -> fixed summation order
+    const int t = lb * BVH_THREADS + tid;
+    const int wave_slot = lb * NW + w;
+    ICP_STAMP(0);
+    const int k = (t < kp.n) ? (qorder ? qorder[t] : t) : -1;
+    const bool seeded = kp.use_prev != 0, inc = kp.incremental && seeded;
+    QueryIn<DIM> in;
+    fused_front_loads<DIM>(kp, pp, bv, k, seeded, inc, in);
+    if constexpr (MERGED) { if (!ring_wait_pose(loop_slot((PoseState*)kp.ps, 0, (int)((blockIdx.x * 2u + (unsigned int)w) % (unsigned int)POSE_REPLICAS)), lane, rp.run_fault, Pm, Nm)) return; }
+    PairOut o; bool searched;
+    fused_search_post<DIM, WIDE>(kp, bv, pp, k, seeded, inc, Pm, Nm, in, bvh_lbq, tid, wave_slot, o, searched);
+    double* partials = pp.partials;
+    fused_block_epilogue(kp, pp, o, bvh_lbq, tid, wave_slot, [=](int a, double v) { partials[(size_t)a * mgrid + lb] = v; });
 }
 template <int DIM, bool WIDE>
 __global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {

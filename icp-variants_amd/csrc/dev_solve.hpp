@@ -531,6 +531,25 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
 //   separate k_reduce_solve launches.  The same happens (PoseState::fault = 2 in the published slot, the rest of the chain passes it on
 //   without touching anything) when a pivot of the 6 x 6 system fails the rank test, i.e. when the solve needs the eigen fallback that
 //   only k_reduce_solve carries (131 VGPRs: it must not ride in the matcher).
+// Thousands of waves polling ONE 128-byte line is a hot spot, not a broadcast: sc1 loads are served behind the L2, one memory channel
+// hands out a line every ~2 ns, so a round of 5 790 polls takes 11 us (measured: 24-28 us per converged iteration with a single slot,
+// against 14 + 7 with one launch per iteration).  Every slot therefore exists POSE_REPLICAS times on lines far enough apart to land on
+// different channels whatever the interleave; block 0 publishes all of them, a wave polls the one its index selects.
+constexpr int POSE_REPLICAS = 64;
+constexpr size_t POSE_REPLICA_STRIDE = 4096 + 128;
+__device__ __host__ __forceinline__ PoseState* loop_slot(PoseState* base, int g, int replica) {
+    return (PoseState*)((char*)base + ((size_t)g * POSE_REPLICAS + (size_t)replica) * POSE_REPLICA_STRIDE);
+}
+#if ICP_DEBUG_TIMES
+#define LOOP_STAMP(slot, j) do { if (L.dbg && g == L.dbg_iter && (threadIdx.x & 63) == 0) L.dbg[8 * (slot) + (j)] = (int)(unsigned int)wall_clock64(); } while (0)
+#else
+#define LOOP_STAMP(slot, j)
+#endif
+// the incoming pose of a run into every replica of slot 0 (one launch instead of POSE_REPLICAS copies)
+__global__ void k_pose_replicas(const PoseState* __restrict__ src, PoseState* slot0) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 32 * POSE_REPLICAS) ((unsigned int*)loop_slot(slot0, 0, t >> 5))[t & 31] = ((const unsigned int*)src)[t & 31];
+}
 constexpr unsigned long long GRANULE_EMPTY = ~0ull;
 #ifndef ICP_RING_SLEEP
 #define ICP_RING_SLEEP 4           // s_sleep argument (x 64 clocks) between two polls of the pose slot by a matcher wave
@@ -538,8 +557,8 @@ constexpr unsigned long long GRANULE_EMPTY = ~0ull;
 struct RingParams {
     const double* red_partials; int red_nblocks;   // partials of the iteration being reduced: [NSUM][red_nblocks]
     unsigned long long* totals_row;                // [NSUM] that iteration's row of the totals ring
-    const PoseState* ps_in;                        // the pose that iteration searched at: complete since the previous launch
-    PoseState* ps_out;                             // slot to publish: the pose the matcher blocks of THIS launch wait for
+    const PoseState* ps_in;                        // the pose that iteration searched at (replica 0 of its slot): complete since the previous launch
+    PoseState* ps_out;                             // slot to publish, POSE_REPLICAS copies of it (loop_slot): the pose the matcher blocks of THIS launch wait for
     icp_iter_stats* stats; int n_src;              // record of the reduced iteration
     int* run_fault;                                // raised by any waiter that ran out of polls
     int n_red;                                     // reducer blocks in front of this grid: 0 (first launch of a run) or NSUM_USED
@@ -560,7 +579,7 @@ __device__ __forceinline__ void ring_reduce_solve(const RingParams& rp) {
     __shared__ int give_up;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, a = blockIdx.x;
     if (a == 0 && rp.ps_in->fault) {                      // the chain was cut further up: pass it on, touch nothing else
-        if (tid < 16) { const unsigned int* src = (const unsigned int*)rp.ps_in; __hip_atomic_store((unsigned long long*)rp.ps_out + tid, granule_of(src[2 * tid], src[2 * tid + 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        { const unsigned int* src = (const unsigned int*)rp.ps_in; for (int q = tid; q < 16 * POSE_REPLICAS; q += RING_THREADS) __hip_atomic_store((unsigned long long*)loop_slot(rp.ps_out, 0, q >> 4) + (q & 15), granule_of(src[2 * (q & 15)], src[2 * (q & 15) + 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         return;
     }
     {
@@ -631,7 +650,8 @@ __device__ __forceinline__ void ring_reduce_solve(const RingParams& rp) {
         slot_words[31] = (unsigned int)fault;
     }
     __syncthreads();
-    if (tid < 16) __hip_atomic_store((unsigned long long*)rp.ps_out + tid, granule_of(slot_words[2 * tid], slot_words[2 * tid + 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int q = tid; q < 16 * POSE_REPLICAS; q += RING_THREADS)      // every replica of the slot, 16 granules each
+        __hip_atomic_store((unsigned long long*)loop_slot(rp.ps_out, 0, q >> 4) + (q & 15), granule_of(slot_words[2 * (q & 15)], slot_words[2 * (q & 15) + 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (rp.stats && !fault) {                             // the record of the reduced iteration (read by the host after the run)
         if (tid < 16) rp.stats->pose[tid] = __uint_as_float(slot_words[tid]);
         if (tid == 16) { rp.stats->n_src = rp.n_src; rp.stats->n_valid = (int)n; rp.stats->rmse = -1.f; rp.stats->benchmark_error = -1.f; rp.stats->status = status; }

@@ -7,7 +7,7 @@
 // fp32 sqrt and divide are correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
 //
 // Files: dev_common.hpp, dev_knn_brute.hpp, dev_bvh.hpp, dev_normals.hpp, dev_projective.hpp, dev_post.hpp, dev_solve.hpp,
-// dev_fused.hpp, dev_measures.hpp (included below, in this order, inside namespace icpdev).
+// dev_fused.hpp, dev_persist.hpp, dev_measures.hpp (included below, in this order, inside namespace icpdev).
 //
 // Kernel map (reference file:line relative to icp-variants/ of the reference):
 //   k_deinterleave      AoS -> SoA upload conversion (+ colour features NearestNeighbor.h:212-221)
@@ -22,6 +22,8 @@
 //                       pruneCorrespondences (ICPOptimizer.h:157-174) + validity filter (:594-610) +
 //                       normal-equation / moment accumulation (ICPOptimizer.h:676-751, ProcrustesAligner.h:43-55)
 //   k_sym_accumulate    second pass of the symmetric objective with the means (ICPOptimizer.h:797-853)
+//   k_icp_loop          the whole loop of one resolution level as ONE launch (point-to-plane, fused BVH matcher): resident waves keep their
+//                       queries in registers, reducer blocks fold / solve / publish the pose through self-validating granules (dev_persist.hpp)
 //   k_reduce_solve      fixed-order reduction of block partials + fp64 solve + pose composition
 //                       (ICPOptimizer.h:614-620,753-781,855-897; ProcrustesAligner.h:56-66)
 //   k_rmse_partial      ConvergenceMeasure::rmseAlignmentError (ConvergenceMeasure.h:50-66)
@@ -42,6 +44,7 @@ namespace icpdev {
 #include "dev_post.hpp"
 #include "dev_solve.hpp"
 #include "dev_fused.hpp"
+#include "dev_persist.hpp"
 #include "dev_measures.hpp"
 
 }  // namespace icpdev

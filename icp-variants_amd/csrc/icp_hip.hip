@@ -13,6 +13,7 @@
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -36,6 +37,7 @@ namespace {
 
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
+    bool view = false;                   // part of another allocation (a plane of a packed level, a section of the search-state pack): never freed on its own
     template <class T> T* as() const { return (T*)p; }
 };
 
@@ -48,7 +50,7 @@ struct Cloud {
 // One resolution level of the source: the selection (original indices, increasing), and -- for the BVH matcher -- a physical
 // copy of the selected points in Morton order, so that everything the ICP loop touches per query (source planes, search
 // state, matches) is indexed by the same sorted position and streams coalesced.  factor 0 = the whole cloud, unfiltered.
-struct Level { DevBuf idx; DevBuf order; DevBuf sorted_idx; Cloud sorted; bool sorted_valid = false; int n = 0; };
+struct Level { DevBuf idx; DevBuf order; DevBuf sorted_idx; DevBuf pack; Cloud sorted; bool sorted_valid = false; int n = 0; };   // pack: the sorted copy's planes in ONE allocation (x y z nx ny nz cr cg cb rgba, a fixed stride apart: k_icp_loop)
 
 // LBVH over the target (buildIndex): device buffers + the host-side facts needed to launch the build.
 struct Bvh {
@@ -79,6 +81,11 @@ struct icp_ctx {
     bool trace = false;                  // ICP_HIP_TRACE=1: per-iteration stage times on stderr
     bool fuse_post = true;               // BVH matcher runs weight / reject / accumulate as its epilogue (ICP_HIP_FUSE_POST=0 disables)
     bool merge_loop = true;              // point-to-plane loop through the fused BVH matcher: reduce + solve ride in front of the next matcher launch (ICP_HIP_MERGE=0: separate k_reduce_solve launches)
+    bool persist_loop = false;           // ICP_HIP_PERSIST=1 (experimental, measured slower than the merged loop so far: DESIGN.md): when the whole grid fits the device at once, the loop of a resolution level as ONE launch (k_icp_loop; ICP_HIP_PERSIST=0 disables)
+    bool shared_gpu = false;             // other contexts work on this device at the same time (icp_batch_run with several contexts): one launch per iteration
+    int loop_runs = 0;                   // runs that took k_icp_loop (icp_debug_counters)
+    hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // k_icp_loop_reducer runs BESIDE the matcher grid: its own stream, forked off / joined to the context's
+    int loop_capacity[4] = {0, 0, 0, 0}; // resident blocks of k_icp_loop<3/6, false/true> on this device (0: not asked yet)
     int merged_runs = 0, merged_fallbacks = 0;   // runs that took the merged loop / that had to be repeated with the separate launches (icp_debug_counters)
     bool keep_fused_records = false;     // icp_match_seeded: the fused matcher also writes its Match records and distances (the loop itself never reads them)
     icp_params prm;
@@ -91,12 +98,10 @@ struct icp_ctx {
     DevBuf okeys, okeys2, ovals, otemp;  // scratch of the Morton sort of the queries
     std::map<int, Level> levels;         // multires selections by decimation factor
     DevBuf sel_lists, sel_counts, sel_blocks;            // RANDOM_SAMPLING: per-iteration index lists, their sizes, scan scratch
+    DevBuf qpack; size_t q_cap = 0;                      // nn_raw | qstate | qstate2 (views below), q_cap elements each
     DevBuf qstate, qstate2;                              // incremental k-NN: per-query anchor + bound on the other targets; bound on the targets outside the neighbour's leaf
     DevBuf dbg_steps;                    // development builds only (ICP_DEBUG_STEPS)
-#if ICP_DEBUG_CUT
-    int dbg_iter = -1;             // development build: the launch of this iteration is cut short (ICP_HIP_DBG_CUT / ICP_HIP_DBG_CUT_ITER) to time its phases
-#endif
-    DevBuf ps, matches, d2, best64, nn_raw, partials, partials2, ring, totals, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
+    DevBuf ps, matches, d2, best64, nn_raw, partials, partials2, ring, pring, totals, sums, stats, staging, rmse_partials, rmse_out, fontana_partials;
     Cloud conv_src, conv_ref; int conv_n = 0;
     float cos_reject = 0.5f;
     std::vector<hipEvent_t> events;
@@ -112,6 +117,7 @@ constexpr int POST_BLOCKS = 512;
 
 int ensure(icp_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap && b.p) return ICP_OK;
+    if (b.view) { b.p = nullptr; b.cap = 0; b.view = false; }      // outgrown: becomes an allocation of its own
     if (b.p) { HIPCK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     size_t want = bytes < 256 ? 256 : bytes;
     HIPCK(c, hipMalloc(&b.p, want));
@@ -126,9 +132,10 @@ int ensure_pinned(icp_ctx* c, size_t bytes) {
     c->pinned_cap = want;
     return ICP_OK;
 }
-void release(DevBuf& b) { if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; } }
+void release(DevBuf& b) { if (b.p && !b.view) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; b.view = false; }
+void set_view(DevBuf& b, void* p, size_t bytes) { release(b); b.p = p; b.cap = bytes; b.view = true; }
 void release(Cloud& c) { release(c.x); release(c.y); release(c.z); release(c.nx); release(c.ny); release(c.nz); release(c.cr); release(c.cg); release(c.cb); release(c.rgba); }
-void release(Level& lv) { release(lv.idx); release(lv.order); release(lv.sorted_idx); release(lv.sorted); lv.sorted_valid = false; }
+void release(Level& lv) { release(lv.idx); release(lv.order); release(lv.sorted_idx); release(lv.sorted); release(lv.pack); lv.sorted_valid = false; }
 
 // Largest float c with (double)acosf(c) > 60*pi/180 on THIS host's libm: the device rejection test
 // `c <= cos_reject` is then bit-identical to the reference's `acos(c) > threshold` (ICPOptimizer.h:161,170)
@@ -153,7 +160,7 @@ int set_device(icp_ctx* c) { HIPCK(c, hipSetDevice(c->device)); return ICP_OK; }
 struct DrainOnError {
     icp_ctx* c; bool ok = false;
     explicit DrainOnError(icp_ctx* ctx) : c(ctx) {}
-    ~DrainOnError() { if (!ok && c && c->stream) (void)hipStreamSynchronize(c->stream); }
+    ~DrainOnError() { if (!ok && c && c->stream) { if (c->stream2) (void)hipStreamSynchronize(c->stream2); (void)hipStreamSynchronize(c->stream); } }
     int done(int rc = ICP_OK) { ok = (rc == ICP_OK); return rc; }
 };
 
@@ -260,10 +267,19 @@ int write_pose(icp_ctx* c, const float pose[16]) {
 }
 
 // One launch of the merged loop: the pose slot its matcher blocks wait for, where they leave their partials, and the reducer that rides in front.
-struct MergeLaunch { RingParams rp; const PoseState* slot; double* partials; };
+struct MergeLaunch { RingParams rp; const PoseState* slot; double* partials; const LoopParams* loop = nullptr; };   // loop != nullptr: k_icp_loop (all iterations of a level in one launch)
 
 struct QuerySet { const Cloud* cl; const int* sel; int n; int pretransformed; bool use_colors; bool seed_prev; const int* order; };   // cl/sel: also what the post stage reads
 
+int ensure_qpack(icp_ctx* c, int n) {
+    if ((size_t)n <= c->q_cap && c->qpack.p) return ICP_OK;
+    int rc;
+    c->q_cap = ((size_t)n + 63) / 64 * 64;
+    if ((rc = ensure(c, c->qpack, c->q_cap * 28))) return rc;
+    set_view(c->nn_raw, c->qpack.p, c->q_cap * 4); set_view(c->qstate, c->qpack.as<char>() + c->q_cap * 4, c->q_cap * 16);
+    set_view(c->qstate2, c->qpack.as<char>() + c->q_cap * 20, c->q_cap * 8);
+    return ICP_OK;
+}
 int ensure_match_buffers(icp_ctx* c, int n) {
     int rc;
     if ((rc = ensure(c, c->matches, (size_t)n * sizeof(icp_match_t)))) return rc;
@@ -441,12 +457,27 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
         PostParams pp = make_post_params(c, *fuse, kp.sel, n);
         KnnParams kf = kp; kf.out = nullptr;
         if (!c->keep_fused_records) { pp.matches = nullptr; kf.d2_out = nullptr; }     // the loop never reads the records of a fused iteration, nor the distances
-#if ICP_DEBUG_CUT
-        { const char* e = getenv("ICP_HIP_DBG_CUT"); const char* f = getenv("ICP_HIP_DBG_CUT_ITER"); kf.nseg = (e && f && atoi(f) == c->dbg_iter) ? 100 + atoi(e) : 1; }
-#endif
         const size_t red_bytes = (size_t)(BVH_THREADS / WAVE) * 33 * 8;           // the reduction reuses the (dead) traversal stacks
         const size_t lds = stack_bytes > red_bytes ? stack_bytes : red_bytes;
-        if (ml) {                                                                  // merged loop: reducer blocks in front, pose through the ring
+        if (ml && ml->loop) {                                                      // the level's whole loop in one launch
+            LoopK<DIM> K; memset(&K, 0, sizeof(K));
+            // (the level's planes and the search state are packed: get_sorted_level / launch_match; anything else cannot take this path)
+            const float* x0 = fuse->x.as<float>(); const long long S = fuse->y.as<float>() - x0;
+            const bool packed_src = S > 0 && fuse->z.as<float>() == x0 + 2 * S && fuse->nx.as<float>() == x0 + 3 * S && fuse->ny.as<float>() == x0 + 4 * S && fuse->nz.as<float>() == x0 + 5 * S &&
+                                    (!fuse->cr.p || (fuse->cr.as<float>() == x0 + 6 * S && fuse->cg.as<float>() == x0 + 7 * S && fuse->cb.as<float>() == x0 + 8 * S && fuse->rgba.as<float>() == x0 + 9 * S));
+            const bool packed_q = kf.nn_raw == c->qpack.as<int>() && (!kf.qstate || (char*)kf.qstate == c->qpack.as<char>() + c->q_cap * 4) && (!kf.qstate2 || (char*)kf.qstate2 == c->qpack.as<char>() + c->q_cap * 20);
+            if (!packed_src || !packed_q || kf.sel || order) { c->err = "k_icp_loop: level or search state not in the packed layout"; return ICP_ERR_INVALID_ARG; }
+            K.src = x0; K.src_stride = (int)S; K.qpack = c->qpack.as<char>(); K.q_cap = (int)c->q_cap;
+            K.leaves = bv.leaves; K.qnodes = bv.qnodes; K.recs = bv.recs; K.Lq = bv.Lq; K.n_valid = bv.n_valid;
+            K.matches = pp.matches; K.d2_out = kf.d2_out; K.dbg_steps = kf.dbg_steps;
+            K.n = kf.n; K.max_dist = kf.max_dist; K.incremental = kf.incremental; K.tier2 = kf.qstate2 ? 1 : 0;
+            K.metric = pp.metric; K.weighting = pp.weighting; K.rejection = pp.rejection; K.cos_reject = pp.cos_reject;
+            K.L = *ml->loop; K.L.nb = nb;
+            const size_t lds_loop = (size_t)LOOP_LDS_ROWS * BVH_THREADS * 8;
+            if (b.Lq <= 8) hipLaunchKernelGGL((k_icp_loop<DIM, false>), dim3(nb), dim3(BVH_THREADS), lds_loop, c->stream, K);
+            else hipLaunchKernelGGL((k_icp_loop<DIM, true>), dim3(nb), dim3(BVH_THREADS), lds_loop, c->stream, K);
+        }
+        else if (ml) {                                                             // merged loop: reducer blocks in front, pose through the ring
             kf.ps = ml->slot; pp.ps = ml->slot; pp.partials = ml->partials;
             if (b.Lq <= 8) hipLaunchKernelGGL((k_knn_bvh_post_ring<DIM, false>), dim3(nb + ml->rp.n_red), dim3(BVH_THREADS), lds, c->stream, kf, bv, order, pp, ml->rp);
             else hipLaunchKernelGGL((k_knn_bvh_post_ring<DIM, true>), dim3(nb + ml->rp.n_red), dim3(BVH_THREADS), lds, c->stream, kf, bv, order, pp, ml->rp);
@@ -486,18 +517,18 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr, con
     kp.tx = c->tgt.x.as<float>(); kp.ty = c->tgt.y.as<float>(); kp.tz = c->tgt.z.as<float>();
     kp.tcr = c->tgt.cr.as<float>(); kp.tcg = c->tgt.cg.as<float>(); kp.tcb = c->tgt.cb.as<float>();
     kp.mpad = c->tgt.npad; kp.ps = c->ps.as<PoseState>(); kp.pretransformed = q.pretransformed; kp.max_dist = p.max_distance;
-    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0; kp.qstate = nullptr; kp.qstate2 = nullptr; kp.incremental = 0; kp.dbg_steps = nullptr;
+    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0; kp.qstate = nullptr; kp.qstate2 = nullptr; kp.incremental = 0; kp.dbg_steps = nullptr; kp.dbg_waves = 0;
     if (p.knn_backend == ICP_KNN_LBVH) {
         kp.nseg = 1;
-        if ((rc = ensure(c, c->nn_raw, (size_t)q.n * 4))) return rc;
+        // neighbour positions and the incremental search's state in ONE allocation, sections a fixed number of elements apart
+        // (int nn_raw[q_cap] | float4 qstate[q_cap] | float2 qstate2[q_cap]): k_icp_loop is handed a base and a stride
+        if ((rc = ensure_qpack(c, q.n))) return rc;
         kp.nn_raw = c->nn_raw.as<int>(); kp.use_prev = q.seed_prev ? 1 : 0;
 #if ICP_DEBUG_STEPS
         if ((rc = ensure(c, c->dbg_steps, (size_t)q.n * 4))) return rc;
-        kp.dbg_steps = c->dbg_steps.as<int>();
+        kp.dbg_steps = c->dbg_steps.as<int>(); kp.dbg_waves = ((q.n + BVH_THREADS - 1) / BVH_THREADS) * (BVH_THREADS / WAVE);
 #endif
         if (p.knn_incremental && !q.pretransformed) {
-            if ((rc = ensure(c, c->qstate, (size_t)q.n * 16))) return rc;
-            if ((rc = ensure(c, c->qstate2, (size_t)q.n * 8))) return rc;
             kp.qstate = c->qstate.as<float4>(); kp.qstate2 = c->tier2 ? c->qstate2.as<float2>() : nullptr; kp.incremental = 1;
         }
         const Cloud* fuse = (fused_blocks != nullptr && p.metric != ICP_METRIC_SYMMETRIC && !q.pretransformed) ? q.cl : nullptr;
@@ -568,6 +599,29 @@ int launch_post_and_solve(icp_ctx* c, const Cloud& src, const int* sel, int n, i
     return ICP_OK;
 }
 
+// How many blocks of k_icp_loop the device holds at once (its waiters wait for blocks of the same grid: the whole grid must be resident).
+template <int DIM, bool WIDE>
+int loop_capacity_of(icp_ctx* c, int* out) {
+    int& cap = c->loop_capacity[(DIM == 6 ? 2 : 0) + (WIDE ? 1 : 0)];
+    if (cap == 0) {
+        int per_cu = 0, cus = 0;
+        const size_t lds = (size_t)LOOP_LDS_ROWS * BVH_THREADS * 8;
+        HIPCK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)&k_icp_loop<DIM, WIDE>, BVH_THREADS, lds));
+        HIPCK(c, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        cap = per_cu * cus > 0 ? per_cu * cus : -1;
+    }
+    *out = cap;
+    return ICP_OK;
+}
+// One k_icp_loop at a time per process: two resident grids that each wait for blocks of their own that the other keeps from being
+// dispatched would wait for each other (bounded, but seconds).  A context that does not get the token runs one launch per iteration.
+std::atomic<int> g_loop_token{0};
+struct LoopToken {
+    bool held = false;
+    bool try_take() { int expect = 0; held = g_loop_token.compare_exchange_strong(expect, 1); return held; }
+    ~LoopToken() { if (held) g_loop_token.store(0); }
+};
+
 int check_ready(icp_ctx* c, bool need_source, bool full_pipeline) {
     const icp_params& p = c->prm;
     if (c->tgt.n <= 0) { c->err = "target index needs to be built before querying (icp_set_target)"; return ICP_ERR_NO_TARGET; }
@@ -636,15 +690,15 @@ int get_sorted_level(icp_ctx* c, int factor, const Cloud** cloud, int* n_out) {
         d.n = n; d.npad = n; d.has_normals = s.has_normals; d.has_colors = s.has_colors;
         DevBuf* dst[9] = {&d.x, &d.y, &d.z, &d.nx, &d.ny, &d.nz, &d.cr, &d.cg, &d.cb};
         const DevBuf* srcp[9] = {&s.x, &s.y, &s.z, &s.nx, &s.ny, &s.nz, &s.cr, &s.cg, &s.cb};
+        const size_t stride = ((size_t)n + 63) / 64 * 64;                         // elements between two planes
+        if ((rc = ensure(c, lv.pack, 10 * stride * 4))) return rc;
+        for (int k = 0; k < 9; k++) set_view(*dst[k], lv.pack.as<float>() + (size_t)k * stride, stride * 4);
+        set_view(d.rgba, lv.pack.as<float>() + 9 * stride, stride * 4);
         for (int k = 0; k < 9; k++) {
             if (!srcp[k]->p) continue;
-            if ((rc = ensure(c, *dst[k], (size_t)n * 4))) return rc;
             hipLaunchKernelGGL(k_gather_f32, g, b, 0, c->stream, srcp[k]->as<float>(), si, n, dst[k]->as<float>());
         }
-        if (s.rgba.p) {
-            if ((rc = ensure(c, d.rgba, (size_t)n * 4))) return rc;
-            hipLaunchKernelGGL(k_gather_u32, g, b, 0, c->stream, s.rgba.as<uint32_t>(), si, n, d.rgba.as<uint32_t>());
-        }
+        if (s.rgba.p) hipLaunchKernelGGL(k_gather_u32, g, b, 0, c->stream, s.rgba.as<uint32_t>(), si, n, d.rgba.as<uint32_t>());
         HIPCK(c, hipGetLastError());
         lv.sorted_valid = true;
     }
@@ -691,6 +745,7 @@ int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out) {
     { const char* e = getenv("ICP_HIP_SPIN_REDUCE"); if (e) c->spin_reduce = e[0] == '1'; }
     { const char* e = getenv("ICP_HIP_TIER2"); if (e && e[0] == '0') c->tier2 = false; }
     { const char* e = getenv("ICP_HIP_MERGE"); if (e && e[0] == '0') c->merge_loop = false; }
+    { const char* e = getenv("ICP_HIP_PERSIST"); if (e) c->persist_loop = e[0] == '1'; }
     { const char* e = getenv("ICP_HIP_PRESORT"); if (e && e[0] == '0') c->presort = false; }
     { const char* e = getenv("ICP_HIP_BLOCK_LEVELS"); if (e && e[0] == '0') c->block_levels = false; }
     { const char* e = getenv("ICP_HIP_TRACE"); if (e && e[0] == '1') c->trace = true; }
@@ -720,7 +775,7 @@ int icp_ctx_destroy(icp_ctx* c) {
     for (Bvh* b : {&c->bvh6, &c->nrm_bvh}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
     release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) release(kv.second);
-    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->qstate2); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->partials2); release(c->ring); release(c->totals); release(c->dbg_steps); release(c->sums);
+    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->qstate2); release(c->qpack); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->partials2); release(c->ring); release(c->pring); release(c->totals); release(c->dbg_steps); release(c->sums);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
     for (DevBuf* d : {&c->src_flag, &c->src_box, &c->tgt_flag, &c->tgt_finite, &c->nrm_finite, &c->sel_temp, &c->d_count}) release(*d);
     if (c->pin_up) (void)hipHostFree(c->pin_up);
@@ -728,6 +783,9 @@ int icp_ctx_destroy(icp_ctx* c) {
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (hipEvent_t e : c->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->build_ev) if (e) (void)hipEventDestroy(e);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->owns_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return ICP_OK;
@@ -866,6 +924,34 @@ int icp_match_seeded(icp_ctx* c, const float* poses, int32_t n_poses, icp_match_
     const Cloud* cloud = nullptr; int n = 0;
     if ((rc = get_sorted_level(c, 0, &cloud, &n))) return rc;
     struct Keep { icp_ctx* c; ~Keep() { c->keep_fused_records = false; } } keep{c};
+    if (c->persist_loop && c->merge_loop && p.metric == ICP_METRIC_POINT_TO_PLANE) {
+        // what icp_run launches for this configuration: k_icp_loop, all the launches' worth of iterations in ONE launch -- here with every pose
+        // slot filled in up front (replica 0 of each; nobody reduces, nobody solves), the last iteration writing its records
+        const int nb = (n + BVH_THREADS - 1) / BVH_THREADS;
+        const size_t slot_bytes = (size_t)(n_poses + 1) * POSE_REPLICAS * POSE_REPLICA_STRIDE;
+        if ((rc = ensure(c, c->ring, slot_bytes + 64))) return rc;
+        if ((rc = ensure(c, c->pring, (size_t)PRING_DEPTH * NSUM_USED * nb * 8))) return rc;
+        PoseState* slots = c->ring.as<PoseState>(); int* fault = (int*)(c->ring.as<char>() + slot_bytes);
+        HIPCK(c, hipMemsetAsync(fault, 0, 64, c->stream));
+        std::vector<PoseState> hp((size_t)n_poses);
+        for (int j = 0; j < n_poses; j++) {
+            memset(&hp[(size_t)j], 0, sizeof(PoseState)); memcpy(hp[(size_t)j].pose, poses + (size_t)16 * j, 64); normal_matrix_from_pose(hp[(size_t)j].pose, hp[(size_t)j].nmat);
+            HIPCK(c, hipMemcpyAsync(loop_slot(slots, j, 0), &hp[(size_t)j], sizeof(PoseState), hipMemcpyHostToDevice, c->stream));
+        }
+        LoopParams L; memset(&L, 0, sizeof(L));
+        L.iters = n_poses; L.first = 0; L.seed_first = 0; L.slots = slots; L.totals = nullptr; L.pring = c->pring.as<unsigned long long>(); L.nb = nb;
+        L.dictated = 1; L.stats = nullptr; L.n_src = n; L.abort_word = fault; L.record_last = 1; L.clocks = nullptr;
+        c->keep_fused_records = true;
+        QuerySet q{cloud, nullptr, n, 0, p.color_icp != 0, false, nullptr};
+        MergeLaunch ml; ml.loop = &L; ml.slot = nullptr; ml.partials = nullptr; memset(&ml.rp, 0, sizeof(ml.rp));
+        int fused = 0;
+        if ((rc = launch_match(c, q, &fused, &ml))) return rc;
+        if (!fused) { c->err = "icp_match_seeded: the matcher did not take the fused path"; return ICP_ERR_INVALID_ARG; }
+        int hf = 0;
+        HIPCK(c, hipMemcpyAsync(&hf, fault, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));           // (hp is read by the copies above)
+        if (hf) { c->err = "icp_match_seeded: k_icp_loop gave up waiting"; return ICP_ERR_HIP; }
+    } else
     for (int j = 0; j < n_poses; j++) {
         if ((rc = write_pose(c, poses + (size_t)16 * j))) return rc;
         c->keep_fused_records = (j == n_poses - 1);
@@ -931,7 +1017,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     if (iters == 0) return guard.done();
     // page-locked staging for the whole run up front: [pose state up | per-iteration records down | pose state down]
     const size_t pin_stats = 256, pin_pose = pin_stats + (((size_t)iters * sizeof(icp_iter_stats) + 255) & ~(size_t)255);
-    if ((rc = ensure_pinned(c, pin_pose + 512))) return rc;
+    if ((rc = ensure_pinned(c, pin_pose + 512 + (size_t)(iters + 1) * 8))) return rc;
     float pose_in[16]; memcpy(pose_in, pose_inout, 64);        // the record of an empty iteration 0 carries the incoming pose
     if ((rc = write_pose(c, pose_inout))) return rc;
     if ((rc = ensure(c, c->stats, (size_t)iters * sizeof(icp_iter_stats)))) return rc;
@@ -979,12 +1065,12 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     // The merged loop (dev_solve.hpp, "the ring form"): point-to-plane through the fused BVH matcher on sorted levels, nothing else on
     // the stream between two iterations.  Launch i = [reducer of iteration i - 1 | matcher of iteration i]; one reducer-only launch closes
     // the run.  Pose slots and totals rows are written once per run; both rings are reset here, so nothing survives an aborted run.
-    bool merged = c->merge_loop && !single && iters >= 2 && sorted_levels && c->fuse_post && p.metric == ICP_METRIC_POINT_TO_PLANE && !rmse && !fontana && !ICP_DEBUG_CUT;
+    bool merged = c->merge_loop && !single && iters >= 2 && sorted_levels && c->fuse_post && p.metric == ICP_METRIC_POINT_TO_PLANE && !rmse && !fontana;
     for (int i = 0; merged && i < iters; i++) if (ns[i] <= 0) merged = false;
     PoseState* slots = nullptr; unsigned long long* trows = nullptr; int* run_fault = nullptr;
     if (merged) {
         static_assert(sizeof(PoseState) == 128, "a pose slot is 16 granules");
-        const size_t slot_bytes = (size_t)(iters + 1) * sizeof(PoseState), tot_bytes = (size_t)iters * NSUM * 8;
+        const size_t slot_bytes = (size_t)(iters + 1) * POSE_REPLICAS * POSE_REPLICA_STRIDE, tot_bytes = (size_t)iters * NSUM * 8;
         int nbmax = POST_BLOCKS;
         for (int i = 0; i < iters; i++) { const int nb = (ns[i] + BVH_THREADS - 1) / BVH_THREADS; if (nb > nbmax) nbmax = nb; }
         if ((rc = ensure(c, c->ring, slot_bytes + tot_bytes + 64))) return rc;
@@ -993,10 +1079,63 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
         slots = c->ring.as<PoseState>(); trows = (unsigned long long*)(c->ring.as<char>() + slot_bytes); run_fault = (int*)(c->ring.as<char>() + slot_bytes + tot_bytes);
         HIPCK(c, hipMemsetAsync(c->ring.p, 0xFF, slot_bytes + tot_bytes, c->stream));
         HIPCK(c, hipMemsetAsync(run_fault, 0, 64, c->stream));
-        HIPCK(c, hipMemcpyAsync(slots, c->ps.p, sizeof(PoseState), hipMemcpyDeviceToDevice, c->stream));      // slot 0 = the incoming pose (write_pose above)
+        hipLaunchKernelGGL(k_pose_replicas, dim3((32 * POSE_REPLICAS + 255) / 256), dim3(256), 0, c->stream, c->ps.as<PoseState>(), slots);      // slot 0 = the incoming pose (write_pose above), every replica
+    }
+    // k_icp_loop (dev_persist.hpp): all iterations of a resolution level in ONE launch, the waves resident from iteration to iteration.
+    // Needs the whole grid on the device at once (its blocks wait for each other) and the device to itself: checked against the kernel's
+    // occupancy; a context marked shared, or one that finds another context's loop in flight, runs one launch per iteration instead.
+    struct Seg { int i0, i1; };
+    std::vector<Seg> segs;
+    LoopToken token;
+    bool persist = merged && c->persist_loop && !c->shared_gpu;
+    long long* d_clocks = nullptr;
+    if (persist) {
+        Bvh& tb = p.color_icp ? c->bvh6 : c->bvh;
+        int cap = -1;
+        if (!tb.valid) persist = false;                    // (built on first use: the first run of such a context takes the per-launch loop)
+        else if (p.color_icp) { if ((rc = tb.Lq <= 8 ? loop_capacity_of<6, false>(c, &cap) : loop_capacity_of<6, true>(c, &cap))) return rc; }
+        else { if ((rc = tb.Lq <= 8 ? loop_capacity_of<3, false>(c, &cap) : loop_capacity_of<3, true>(c, &cap))) return rc; }
+        int nbmax = 1;
+        for (int i = 0; persist && i < iters; ) {
+            int j = i + 1;
+            while (j < iters && clouds[j] == clouds[i] && ns[j] == ns[i] && factors[j] == factors[i]) j++;
+            const int nb = (ns[i] + BVH_THREADS - 1) / BVH_THREADS;
+            if (nb + LOOP_RED > cap) persist = false;      // (the reducer's two-wave blocks sit in the holes the matcher grid leaves: dev_persist.hpp)
+            if (nb > nbmax) nbmax = nb;
+            segs.push_back(Seg{i, j});
+            i = j;
+        }
+        if (persist && !token.try_take()) persist = false;
+        if (persist) {
+            // every buffer the launches below touch is sized for the largest level NOW: an allocation that grows between two launches frees its
+            // old block, and hipFree waits for the device -- for a reducer kernel that is itself waiting for the matcher launch still to come
+            { int nmax = 1; for (int i = 0; i < iters; i++) if (ns[i] > nmax) nmax = ns[i];
+              if ((rc = ensure_match_buffers(c, nmax))) return rc;
+              if ((rc = ensure_qpack(c, nmax))) return rc;
+              if ((rc = ensure(c, c->partials, (size_t)(nbmax > POST_BLOCKS ? nbmax : POST_BLOCKS) * NSUM * 8))) return rc; }
+            size_t pring_granules = 0;
+            for (const Seg& sg : segs) pring_granules += (size_t)PRING_DEPTH * NSUM_USED * ((ns[sg.i0] + BVH_THREADS - 1) / BVH_THREADS);
+            if ((rc = ensure(c, c->pring, pring_granules * 8))) return rc;
+            HIPCK(c, hipMemsetAsync(c->pring.p, 0xFF, pring_granules * 8, c->stream));
+            if (!c->stream2) {
+                HIPCK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+                HIPCK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                HIPCK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+            }
+            // its own rings: [pose slots x POSE_REPLICAS | totals | fault word | clocks]
+            const size_t slot_bytes = (size_t)(iters + 1) * POSE_REPLICAS * POSE_REPLICA_STRIDE, tot_bytes = (size_t)iters * TOTALS_ROW * 8, clk_bytes = (size_t)(iters + 1) * 8;
+            if ((rc = ensure(c, c->ring, slot_bytes + tot_bytes + 64 + clk_bytes))) return rc;
+            slots = c->ring.as<PoseState>(); trows = (unsigned long long*)(c->ring.as<char>() + slot_bytes); run_fault = (int*)(c->ring.as<char>() + slot_bytes + tot_bytes);
+            d_clocks = (long long*)(c->ring.as<char>() + slot_bytes + tot_bytes + 64);
+            HIPCK(c, hipMemsetAsync(c->ring.p, 0xFF, slot_bytes + tot_bytes, c->stream));
+            HIPCK(c, hipMemsetAsync(run_fault, 0, 64 + clk_bytes, c->stream));
+            hipLaunchKernelGGL(k_pose_replicas, dim3((32 * POSE_REPLICAS + 255) / 256), dim3(256), 0, c->stream, c->ps.as<PoseState>(), slots);      // slot 0 = the incoming pose, every replica
+        }
     }
     // Stage timing (TimeMeasure.h:20-26).  A HIP event costs ~4 us of stream time, two to three per iteration are ~10 % of a
     // 0.07 ms iteration: mode N > 1 brackets only every Nth iteration (offset rotating from run to run) and scales the sums.
+    // (k_icp_loop: no events inside a launch -- its reducer block 0 leaves the 100 MHz clock at every pose it publishes instead:
+    //  "match" of iteration i = the time from pose i to pose i + 1, every iteration, at no cost.)
     // Event slots: 4 per iteration (start, after match, after post, end) + run start / run end.  In the merged loop an iteration is ONE
     // launch (its reduce + solve happen inside the next one): "match" is that launch, "solve" only the closing reducer-only launch.
     const int tmode = c->stage_timing;
@@ -1012,14 +1151,42 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
         if (i > 0) {
             rp.n_red = NSUM_USED;
             rp.red_partials = ((i - 1) & 1) ? c->partials2.as<double>() : c->partials.as<double>(); rp.red_nblocks = (ns[i - 1] + BVH_THREADS - 1) / BVH_THREADS;
-            rp.totals_row = trows + (size_t)(i - 1) * NSUM; rp.ps_in = slots + (i - 1); rp.ps_out = slots + i;
+            rp.totals_row = trows + (size_t)(i - 1) * NSUM; rp.ps_in = loop_slot(slots, i - 1, 0); rp.ps_out = loop_slot(slots, i, 0);
             rp.stats = c->stats.as<icp_iter_stats>() + (i - 1); rp.n_src = ns[i - 1];
         }
         return rp;
     };
     if (!merged && (rc = rearm_handover(c))) return rc;
     HIPCK(c, hipEventRecord(c->events[0], c->stream));
-    for (int i = 0; i < iters; i++) {
+    if (persist) {
+        // every level: the reducer on the second stream (forked off here, joined below), the matcher grid on the context's; each level has
+        // its own section of the partial ring, so that a level's matcher never writes where the level before is still being re-armed
+        HIPCK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        size_t pring_off = 0;
+        for (const Seg& sg : segs) {
+            const int i = sg.i0, nb = (ns[i] + BVH_THREADS - 1) / BVH_THREADS;
+            LoopParams L; memset(&L, 0, sizeof(L));
+            L.iters = sg.i1 - sg.i0; L.first = i; L.seed_first = 0; L.slots = slots; L.totals = trows; L.pring = c->pring.as<unsigned long long>() + pring_off; L.nb = nb;
+            { const char* e = getenv("ICP_HIP_LOOP_PRESLEEP"); L.presleep_eighths = e ? atoi(e) : 3; }
+            L.dictated = 0; L.stats = c->stats.as<icp_iter_stats>(); L.n_src = ns[i]; L.abort_word = run_fault; L.record_last = 0; L.clocks = d_clocks;
+#if ICP_DEBUG_TIMES
+            if ((rc = ensure(c, c->dbg_steps, (size_t)(ns[i] > 65536 ? ns[i] : 65536) * 4))) return rc;
+            L.dbg = c->dbg_steps.as<int>(); L.dbg_waves = nb * (BVH_THREADS / WAVE); { const char* e = getenv("ICP_HIP_DBG_ITER"); L.dbg_iter = e ? atoi(e) : -1; }
+#endif
+            pring_off += (size_t)PRING_DEPTH * NSUM_USED * nb;
+            QuerySet q{clouds[i], sels[i], ns[i], 0, p.color_icp != 0, false, orders[i]};
+            MergeLaunch ml; ml.loop = &L; ml.slot = nullptr; ml.partials = nullptr; memset(&ml.rp, 0, sizeof(ml.rp));
+            int fused = 0;
+            if ((rc = launch_match(c, q, &fused, &ml))) return rc;      // (first: nothing on the host may block between the two launches of a level)
+            if (!fused) { c->err = "k_icp_loop: the matcher did not take the fused path"; return ICP_ERR_HIP; }
+            hipLaunchKernelGGL(k_icp_loop_reducer, dim3(LOOP_RED), dim3(RING_THREADS), 0, c->stream2, L);
+            HIPCK(c, hipGetLastError());
+        }
+        HIPCK(c, hipEventRecord(c->ev_join, c->stream2));
+        HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    }
+    for (int i = 0; i < iters && !persist; i++) {
         icp_iter_stats* d_st = c->stats.as<icp_iter_stats>() + i;
         const bool ev = sampled[i] != 0;
         if (ev && !(i > 0 && sampled[i - 1])) HIPCK(c, hipEventRecord(E(i, 0), c->stream));
@@ -1028,11 +1195,8 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
             const bool seed = i > 0 && factors[i] == factors[i - 1] && ns[i - 1] > 0 && p.selection == 0;
             QuerySet q{clouds[i], sels[i], ns[i], 0, p.color_icp != 0 && p.matching == ICP_MATCH_KNN, seed, orders[i]};
             int fused = 0;
-#if ICP_DEBUG_CUT
-            c->dbg_iter = i;
-#endif
             MergeLaunch ml;
-            if (merged) { ml.rp = ring_params(i); ml.slot = slots + i; ml.partials = (i & 1) ? c->partials2.as<double>() : c->partials.as<double>(); }
+            if (merged) { ml.rp = ring_params(i); ml.slot = loop_slot(slots, i, 0); ml.partials = (i & 1) ? c->partials2.as<double>() : c->partials.as<double>(); }
             if ((rc = launch_match(c, q, c->fuse_post ? &fused : nullptr, merged ? &ml : nullptr))) return rc;
             if (merged && !fused) { c->err = "merged loop: the matcher did not take the fused path"; return ICP_ERR_HIP; }
             if (ev) HIPCK(c, hipEventRecord(E(i, 1), c->stream));
@@ -1058,24 +1222,28 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     }
     HIPCK(c, hipEventRecord(c->events[1], c->stream));
     std::vector<icp_iter_stats> hs((size_t)iters);
-    const PoseState* d_final = merged ? slots + iters : c->ps.as<PoseState>();
+    const PoseState* d_final = merged ? loop_slot(slots, iters, 0) : c->ps.as<PoseState>();
+    if (persist) HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_pose + 192, d_clocks, (size_t)(iters + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_stats, c->stats.p, (size_t)iters * sizeof(icp_iter_stats), hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_pose, d_final, sizeof(PoseState), hipMemcpyDeviceToHost, c->stream));
     if (merged) HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_pose + 128, run_fault, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     if (merged) {
-        c->merged_runs++;
+        if (persist) c->loop_runs++; else c->merged_runs++;
         const PoseState* hp = (const PoseState*)((char*)c->pinned + pin_pose);
         const int rf = *(const int*)((char*)c->pinned + pin_pose + 128);
         if (hp->fault || rf) {
             // a pivot of the 6 x 6 system failed the rank test (the eigen fallback lives in k_reduce_solve only), or a bounded wait ran out:
             // the same run again, from the incoming pose, with the separate launches
             c->merged_fallbacks++;
+            if (c->trace) fprintf(stderr, "[icp_hip] %s gave up: slot fault %d, abort word %d -> the run again with separate launches\n", persist ? "k_icp_loop" : "merged loop", hp->fault, rf);
             guard.ok = true;                                 // synchronised
             memcpy(pose_inout, pose_in, 64);
+            const bool m0 = c->merge_loop;
             c->merge_loop = false;
+            token.~LoopToken(); token.held = false;
             const int rc2 = run_loop(c, pose_inout, stats, max_stats, n_run, single);
-            c->merge_loop = true;
+            c->merge_loop = m0;
             return rc2;
         }
     }
@@ -1094,7 +1262,16 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     icp_timing& t = c->timing; memset(&t, 0, sizeof(t)); t.iterations = iters;
     int n_sampled = 0;
     c->it_match_ms.assign((size_t)iters, -1.f); c->it_post_ms.assign((size_t)iters, -1.f); c->it_solve_ms.assign((size_t)iters, -1.f);
-    for (int i = 0; i < iters; i++) {
+    if (persist) {                                        // the device's own clock at every published pose: 100 MHz ticks
+        const long long* clk = (const long long*)((char*)c->pinned + pin_pose + 192);
+        for (int i = 0; i < iters; i++) {
+            const float a = (float)((double)(clk[i + 1] - clk[i]) * 1e-5);
+            t.match_ms += a; c->it_match_ms[(size_t)i] = a; c->it_post_ms[(size_t)i] = 0.f; c->it_solve_ms[(size_t)i] = 0.f;
+            if (c->trace) fprintf(stderr, "[icp_hip] it %2d  n %d  iteration %.4f ms (k_icp_loop)\n", i, ns[i], a);
+        }
+        n_sampled = iters;
+    }
+    for (int i = 0; i < iters && !persist; i++) {
         if (!sampled[i]) continue;
         n_sampled++;
         float a = 0, b = 0, d = 0;
@@ -1308,7 +1485,7 @@ int icp_debug_steps(icp_ctx* c, int32_t* out, int32_t n) {
 //                               short between a block's publish and block 0's re-arm would leave behind.  The next call must not see it.
 int icp_debug_counters(icp_ctx* c, int32_t* merged_runs, int32_t* merged_fallbacks) {
     if (!c) return ICP_ERR_INVALID_ARG;
-    if (merged_runs) *merged_runs = c->merged_runs;
+    if (merged_runs) *merged_runs = c->merged_runs + c->loop_runs;
     if (merged_fallbacks) *merged_fallbacks = c->merged_fallbacks;
     return ICP_OK;
 }

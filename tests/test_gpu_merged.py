@@ -1,8 +1,10 @@
-"""The merged loop (dev_solve.hpp "the ring form": the reducer of iteration i - 1 rides in front of the matcher launch of iteration i,
-the pose travels through self-validating granules) against the loop with separate k_reduce_solve launches (ICP_HIP_MERGE=0): the fold
-order and the solve are the same operations, so every iteration's pose and valid count must be equal bit for bit -- any stale or torn
-hand-over shows up as a different pose.  Plus the routes out of the merged loop (rank-deficient system -> repeated with the separate
-launches; an iteration without correspondences) and the re-arming of k_reduce_solve's own hand-over slots."""
+"""The three forms of the point-to-plane loop -- "loop": k_icp_loop, all iterations of a level in ONE launch beside its reducer kernel
+(dev_persist.hpp; ICP_HIP_PERSIST=1); "merged": one launch per iteration with the reducer of iteration i - 1 riding in front of the
+matcher of iteration i (dev_solve.hpp "the ring form"; the default); "separate": k_reduce_solve as a launch of its own (ICP_HIP_MERGE=0).
+In all of them the pose and the sums travel through self-validating granules or kernel boundaries, the fold order and the solve are
+the same operations, so every iteration's pose and valid count must be equal bit for bit -- any stale or torn hand-over shows up as a
+different pose.  Plus the routes out of the first two (rank-deficient system -> repeated with the separate launches; an iteration
+without correspondences) and the re-arming of k_reduce_solve's own hand-over slots."""
 import ctypes as C
 import os
 import numpy as np
@@ -13,16 +15,25 @@ f32 = np.float32
 LBVH = 1
 
 
-def make_ctx(factory, merge, **params):
-    old = os.environ.get("ICP_HIP_MERGE")
-    os.environ["ICP_HIP_MERGE"] = "1" if merge else "0"          # read once, at icp_ctx_create
+FORMS = ("loop", "merged", "separate")
+
+
+def make_ctx(factory, form, **params):
+    if form is True:
+        form = "merged"
+    elif form is False:
+        form = "separate"
+    env = {"ICP_HIP_MERGE": "0" if form == "separate" else "1", "ICP_HIP_PERSIST": "1" if form == "loop" else "0"}      # read once, at icp_ctx_create
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
         c = factory()
     finally:
-        if old is None:
-            del os.environ["ICP_HIP_MERGE"]
-        else:
-            os.environ["ICP_HIP_MERGE"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     c.params.knn_backend = LBVH; c.params.metric = 1
     for k, v in params.items():
         setattr(c.params, k, v)
@@ -47,8 +58,8 @@ def test_merged_loop_fullsize_is_bit_identical_to_separate_launches(gpu_ctx_fact
     from icp_amd import synth
     p = synth.eth_like_pair(0)
     out = []
-    for merge in (True, False):
-        c = make_ctx(gpu_ctx_factory, merge, max_distance=10.0, n_iterations=50)
+    for form in FORMS:
+        c = make_ctx(gpu_ctx_factory, form, max_distance=10.0, n_iterations=50)
         c.set_target(p["tgt_pts"], p["tgt_nrm"]); c.set_source(p["src_pts"], p["src_nrm"])
         for stage_timing in (0, 1, 7):                          # the event brackets sit between the launches: they must not matter
             c.set_stage_timing(stage_timing)
@@ -56,7 +67,10 @@ def test_merged_loop_fullsize_is_bit_identical_to_separate_launches(gpu_ctx_fact
             assert rc == 0 and len(recs) == 50
             out.append((pose, recs))
         runs, fallbacks = counters(c)
-        assert (runs, fallbacks) == ((3, 0) if merge else (0, 0))
+        assert (runs, fallbacks) == ((0, 0) if form == "separate" else (3, 0))
+        if form == "loop":                                      # its iteration times come from the device's own clock, every iteration
+            a, _, _ = c.iteration_times()
+            assert len(a) == 50 and (a > 0).all() and a[0] > a[-1]
         t = c.timing()
         assert t["iterations"] == 50 and t["match_ms"] > 0
         c.close()
@@ -80,16 +94,18 @@ def test_merged_loop_small_cases(gpu_ctx_factory, bunny, case):
         tgt = synth.compact_valid(r["tgt_pts"], r["tgt_nrm"], r["tgt_rgba"]); src = synth.compact_valid(r["src_pts"], r["src_nrm"], r["src_rgba"])
         kw.update(max_distance=0.1, color_icp=1, weighting=3, n_iterations=25)
     res = []
-    for merge in (True, False):
-        c = make_ctx(gpu_ctx_factory, merge, **kw)
+    for form in FORMS:
+        c = make_ctx(gpu_ctx_factory, form, **kw)
         c.set_target(*tgt); c.set_source(*src)
         pose, recs, rc = c.run(np.eye(4), check=False)
         res.append((rc, pose, recs, counters(c)))
         c.close()
-    assert res[0][0] == res[1][0]
-    assert np.array_equal(res[0][1], res[1][1])
-    assert_same_run(res[0][2], res[1][2])
-    assert res[0][3] == (1, 0) and res[1][3] == (0, 0)
+    for r in res[:2]:
+        assert r[0] == res[2][0]
+        assert np.array_equal(r[1], res[2][1])
+        assert_same_run(r[2], res[2][2])
+        assert r[3] == (1, 0)
+    assert res[2][3] == (0, 0)
 
 
 def test_rank_deficient_system_leaves_the_merged_loop(gpu_ctx_factory, bunny):
@@ -99,7 +115,7 @@ def test_rank_deficient_system_leaves_the_merged_loop(gpu_ctx_factory, bunny):
     sp = (tp[:40] + f32(1.0)).copy(); sn = tn[:40].copy()          # 39 sources a metre away from everything ...
     sp[7] = tp[7] + f32(1e-4)                                      # ... and one on the surface
     res = []
-    for merge in (True, False):
+    for merge in ("loop", "separate", "merged", "separate"):
         c = make_ctx(gpu_ctx_factory, merge, max_distance=0.0003, n_iterations=6, rejection=0)
         c.set_target(tp, tn); c.set_source(sp, sn)
         pose, recs, rc = c.run(np.eye(4), check=False)
@@ -108,9 +124,10 @@ def test_rank_deficient_system_leaves_the_merged_loop(gpu_ctx_factory, bunny):
         assert rc2 == rc and np.array_equal(pose2, pose)
         c.close()
     assert res[0][2][0]["n_valid"] == 1
-    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
-    assert_same_run(res[0][2], res[1][2])
-    assert res[0][3][0] == 1 and res[0][3][1] == 1                # one merged run, one fallback (the second run starts merged again: counted before close)
+    for a in (0, 2):
+        assert res[a][0] == res[1][0] and np.array_equal(res[a][1], res[1][1])
+        assert_same_run(res[a][2], res[1][2])
+        assert res[a][3] == (1, 1)                              # one run in that form, one fallback (counted before the second run)
 
 
 def test_iteration_without_correspondences_in_the_merged_loop(gpu_ctx_factory, bunny):
@@ -118,7 +135,7 @@ def test_iteration_without_correspondences_in_the_merged_loop(gpu_ctx_factory, b
     ICPOptimizer.h:680) -- inside the merged loop, without a fallback."""
     from icp_amd import binding
     res = []
-    for merge in (True, False):
+    for merge in ("loop", "separate", "merged"):
         c = make_ctx(gpu_ctx_factory, merge, max_distance=1e-12, n_iterations=4)
         c.set_target(bunny["tgt_pts"], bunny["tgt_nrm"]); c.set_source(bunny["src_pts"] + f32(3.0), bunny["src_nrm"])
         pose, recs, rc = c.run(np.eye(4), check=False)
@@ -126,8 +143,8 @@ def test_iteration_without_correspondences_in_the_merged_loop(gpu_ctx_factory, b
         assert all(r["status"] == binding.ERR_NO_CORRESPONDENCES and r["n_valid"] == 0 for r in recs) and len(recs) == 4
         res.append((recs, counters(c)))
         c.close()
-    assert_same_run(res[0][0], res[1][0])
-    assert res[0][1] == (1, 0)
+    assert_same_run(res[0][0], res[1][0]); assert_same_run(res[2][0], res[1][0])
+    assert res[0][1] == (1, 0) and res[2][1] == (1, 0)
 
 
 def test_stale_total_in_the_handover_slots_is_never_consumed(gpu_ctx_factory, bunny):

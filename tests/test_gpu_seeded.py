@@ -30,8 +30,17 @@ def eth_oracle_run(eth_pair, orc):
     return kd, poses, recs
 
 
-def make_ctx(factory, pair, rejection, **kw):
-    c = factory()
+def make_ctx(factory, pair, rejection, loop=False, **kw):
+    import os
+    old = os.environ.get("ICP_HIP_PERSIST")
+    os.environ["ICP_HIP_PERSIST"] = "1" if loop else "0"     # icp_match_seeded then drives k_icp_loop (all launches' worth in ONE launch) with the poses dictated
+    try:
+        c = factory()
+    finally:
+        if old is None:
+            del os.environ["ICP_HIP_PERSIST"]
+        else:
+            os.environ["ICP_HIP_PERSIST"] = old
     c.params.max_distance = 10.0; c.params.metric = 1; c.params.n_iterations = 50; c.params.knn_backend = LBVH; c.params.rejection = rejection
     for k, v in kw.items():
         setattr(c.params, k, v)
@@ -40,12 +49,13 @@ def make_ctx(factory, pair, rejection, **kw):
     return c
 
 
-@pytest.mark.parametrize("upto", [1, 5, 12, 30])
-def test_seeded_search_fullsize_bit_exact_vs_kdtree_oracle(gpu_ctx_factory, eth_pair, eth_oracle_run, orc, upto):
+@pytest.mark.parametrize("upto,loop", [(1, False), (5, False), (12, False), (30, False), (5, True), (30, True)])
+def test_seeded_search_fullsize_bit_exact_vs_kdtree_oracle(gpu_ctx_factory, eth_pair, eth_oracle_run, orc, upto, loop):
     """370 488 x 370 488, the oracle's own pose sequence of iterations 0..upto replayed through the fused matcher: the records of launch
-    `upto` -- reached through `upto` seeded, incremental launches -- equal the oracle's kd-tree search at that pose, idx and d2 bits."""
+    `upto` -- reached through `upto` seeded, incremental launches (loop: iterations of ONE k_icp_loop launch, the waves resident, their
+    queries' data parked from iteration to iteration) -- equal the oracle's kd-tree search at that pose, idx and d2 bits."""
     kd, poses, _ = eth_oracle_run
-    c = make_ctx(gpu_ctx_factory, eth_pair, rejection=0)
+    c = make_ctx(gpu_ctx_factory, eth_pair, rejection=0, loop=loop)
     m, d2 = c.match_seeded(poses[: upto + 1])
     mo, do = kd.query(orc.transform_points(eth_pair["src_pts"], poses[upto]), 10.0)
     assert np.array_equal(m["idx"], mo["idx"]), int((m["idx"] != mo["idx"]).sum())
