@@ -89,21 +89,86 @@ __device__ __forceinline__ bool loop_wait_pose(const LoopParams& L, const PoseSt
 // word raised, the host repeats the run with one launch per iteration.
 constexpr int LOOP_RED = 2 * NSUM_USED;
 constexpr int TOTALS_ROW = 128;                           // granules per iteration in the totals ring: 3 per sum, padded
-__global__ __launch_bounds__(RING_THREADS) void k_icp_loop_reducer(const LoopParams L) {
+// The solver: block LOOP_RED of the reducer grid, ONE wave (its second wave leaves at once: every barrier below is then a barrier of one
+// wave, and the lane-parallel solve's dozen of them cost nothing).  Polls the 3 x 34 partial totals, folds them in k_reduce_solve's order,
+// solves, publishes the pose into every replica of slot g + 1 and the record of iteration g.
+__device__ __forceinline__ void loop_solver(const LoopParams& L) {
     __shared__ double tot[NSUM];
     __shared__ double parts[NSUM_USED][3];
-    __shared__ double wsum[2];
     __shared__ unsigned int slot_words[32];
+    const int tid = threadIdx.x;
+    if (tid >= WAVE) return;
+    if (tid == 0 && L.clocks) L.clocks[L.first] = (long long)wall_clock64();
+    for (int it = 0; it < L.iters; it++) {
+        const int g = L.first + it;
+        const unsigned long long* trow = L.totals + (size_t)g * TOTALS_ROW;
+        bool lost = false;
+        for (int q = tid; q < 3 * NSUM_USED; q += WAVE) {
+            unsigned long long bits = GRANULE_EMPTY;
+            for (int spin = 0; spin < SPIN_LIMIT; spin++) {
+                bits = __hip_atomic_load(trow + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (bits != GRANULE_EMPTY) break;
+                __builtin_amdgcn_s_sleep(2);
+                if ((spin & 63) == 63 && loop_aborted(L)) break;
+            }
+            if (bits == GRANULE_EMPTY) lost = true;
+            parts[q / 3][q % 3] = __longlong_as_double((long long)bits);
+        }
+        LOOP_STAMP(L.dbg_waves + 2 * LOOP_RED, 3);
+        const bool give_up = __any(lost);
+        __syncthreads();
+        if (tid < NSUM) tot[tid] = tid < NSUM_USED ? (parts[tid][0] + parts[tid][1]) + parts[tid][2] : 0.0;
+        __syncthreads();
+        const PoseState* pin = loop_slot(L.slots, g, 0);    // complete: this wave published it (or the host did, g = first)
+        const double n = tot[SUM_N];
+        int fault = 0, status = ICP_OK;
+        const float* npose = nullptr;
+        if (give_up) fault = 1;
+        else if (n > 0) { npose = p2plane_lanes_core(tot + SUM_M, pin->pose); if (!npose) fault = 2; }      // (uniform)
+        else status = ICP_ERR_NO_CORRESPONDENCES;          // the pose stays (ICPOptimizer.h:668,680: the reference would hang in ASSERT)
+        if (tid < 16) slot_words[tid] = __float_as_uint(npose ? npose[tid] : pin->pose[tid]);
+        if (tid == 32) {
+            float nm[9];
+            if (npose) normal_matrix_from_pose(npose, nm); else for (int q = 0; q < 9; q++) nm[q] = pin->nmat[q];
+            for (int q = 0; q < 9; q++) slot_words[16 + q] = __float_as_uint(nm[q]);
+        }
+        if (tid == 33) {
+            for (int k = 0; k < 3; k++) {
+                slot_words[25 + k] = __float_as_uint(n > 0 ? (float)(tot[SUM_S + k] / n) : 0.f);
+                slot_words[28 + k] = __float_as_uint(n > 0 ? (float)(tot[SUM_D + k] / n) : 0.f);
+            }
+            slot_words[31] = (unsigned int)fault;
+        }
+        __syncthreads();
+        if (fault && tid == 0) loop_abort(L, fault);
+        if (tid == 0 && L.clocks) L.clocks[g + 1] = (long long)wall_clock64();
+        for (int q = tid; q < 16 * POSE_REPLICAS; q += WAVE)          // every replica, 16 granules each
+            __hip_atomic_store((unsigned long long*)loop_slot(L.slots, g + 1, q >> 4) + (q & 15), granule_of(slot_words[2 * (q & 15)], slot_words[2 * (q & 15) + 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        LOOP_STAMP(L.dbg_waves + 2 * LOOP_RED, 4);
+#if ICP_DEBUG_TIMES
+        if (L.dbg && g == L.dbg_iter - 1 && tid == 0) L.dbg[8 * (L.dbg_waves + 2 * LOOP_RED + 2)] = (int)(unsigned int)wall_clock64();      // when the pose of the stamped iteration went out
+#endif
+        if (L.stats && !fault) {
+            icp_iter_stats* st = L.stats + g;
+            if (tid < 16) st->pose[tid] = __uint_as_float(slot_words[tid]);
+            if (tid == 16) { st->n_src = L.n_src; st->n_valid = (int)n; st->rmse = -1.f; st->benchmark_error = -1.f; st->status = status; }
+        }
+        if (fault) return;
+        __syncthreads();                                   // slot_words / tot are rewritten by the next iteration
+    }
+}
+
+__global__ __launch_bounds__(RING_THREADS) void k_icp_loop_reducer(const LoopParams L) {
+    __shared__ double wsum[2];
     __shared__ int give_up;
+    if ((int)blockIdx.x == LOOP_RED) { loop_solver(L); return; }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, a = (int)blockIdx.x >> 1, h = (int)blockIdx.x & 1;
-    const bool solver = blockIdx.x == 0;
     long long t_prev = 0, period = 0;                      // clock (100 MHz) at the end of the last fold, and the time between the last two
-    if (solver && tid == 0 && L.clocks) L.clocks[L.first] = (long long)wall_clock64();
     for (int it = 0; it < L.iters; it++) {
         const int g = L.first + it;
         unsigned long long* row = L.pring + ((size_t)(it % PRING_DEPTH) * NSUM_USED + a) * L.nb;
         const int tb = h * RING_THREADS + tid;              // this thread's granules: row[j * 256 + tb]
-        // Most of an iteration nothing can have arrived: sleep through a part of the last period (3/8: iteration 1 lasts half as long as the
+        // Most of an iteration nothing can have arrived: sleep through a part of the last period (iteration 1 lasts half as long as the
         // unseeded iteration 0; from then on the periods shrink slowly) before the first poll.
         if (period > 0) { const long long until = t_prev + ((period * L.presleep_eighths) >> 3); while ((long long)wall_clock64() < until) __builtin_amdgcn_s_sleep(32); }
         LOOP_STAMP(L.dbg_waves + 2 * (int)blockIdx.x + w, 0);
@@ -126,7 +191,7 @@ __global__ __launch_bounds__(RING_THREADS) void k_icp_loop_reducer(const LoopPar
                     if (v[j] == GRANULE_EMPTY) { v[j] = __hip_atomic_load(row + b0 + j * SOLVE_THREADS + tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); miss = true; }
                 }
                 if (!miss) break;
-                if (spin < 16) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(32);
+                if (spin < 64) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(32);
                 if ((spin & 31) == 31 && loop_aborted(L)) { lost = true; break; }
                 if (spin == limit - 1) { lost = true; loop_abort(L, 1); }
             }
@@ -151,62 +216,9 @@ __global__ __launch_bounds__(RING_THREADS) void k_icp_loop_reducer(const LoopPar
                 __hip_atomic_store(trow + 3 * a + 2, granule_of((unsigned int)b3, (unsigned int)(b3 >> 32)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        LOOP_STAMP(L.dbg_waves + 2 * (int)blockIdx.x + w, 2);
         // the consumed granules back to "empty" -- behind the total in the memory pipeline, not in front of it
         for (int b = tb; b < L.nb; b += SOLVE_THREADS) __hip_atomic_store(row + b, GRANULE_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        LOOP_STAMP(L.dbg_waves + 2 * (int)blockIdx.x + w, 2);
-        if (!solver) continue;
-        // ---- block 0: the 3 x 34 partial totals -> solve -> pose slot g + 1
-        if (tid < 3 * NSUM_USED) {
-            unsigned long long bits = GRANULE_EMPTY;
-            for (int spin = 0; spin < SPIN_LIMIT; spin++) {
-                bits = __hip_atomic_load(trow + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (bits != GRANULE_EMPTY) break;
-                __builtin_amdgcn_s_sleep(2);
-                if ((spin & 63) == 63 && loop_aborted(L)) break;
-            }
-            if (bits == GRANULE_EMPTY) give_up = 1;
-            parts[tid / 3][tid % 3] = __longlong_as_double((long long)bits);
-        }
-        LOOP_STAMP(L.dbg_waves + 2 * (int)blockIdx.x + w, 3);
-        __syncthreads();
-        if (tid < NSUM) tot[tid] = tid < NSUM_USED ? (parts[tid][0] + parts[tid][1]) + parts[tid][2] : 0.0;
-        __syncthreads();
-        const PoseState* pin = loop_slot(L.slots, g, 0);    // complete: this block published it (or the host did, g = first)
-        const double n = tot[SUM_N];
-        int fault = 0, status = ICP_OK;
-        const float* npose = nullptr;
-        if (give_up) fault = 1;
-        else if (n > 0) { npose = p2plane_lanes_core(tot + SUM_M, pin->pose); if (!npose) fault = 2; }      // (uniform)
-        else status = ICP_ERR_NO_CORRESPONDENCES;          // the pose stays (ICPOptimizer.h:668,680: the reference would hang in ASSERT)
-        if (tid < 16) slot_words[tid] = __float_as_uint(npose ? npose[tid] : pin->pose[tid]);
-        if (tid == 32) {
-            float nm[9];
-            if (npose) normal_matrix_from_pose(npose, nm); else for (int q = 0; q < 9; q++) nm[q] = pin->nmat[q];
-            for (int q = 0; q < 9; q++) slot_words[16 + q] = __float_as_uint(nm[q]);
-        }
-        if (tid == 33) {
-            for (int k = 0; k < 3; k++) {
-                slot_words[25 + k] = __float_as_uint(n > 0 ? (float)(tot[SUM_S + k] / n) : 0.f);
-                slot_words[28 + k] = __float_as_uint(n > 0 ? (float)(tot[SUM_D + k] / n) : 0.f);
-            }
-            slot_words[31] = (unsigned int)fault;
-        }
-        __syncthreads();
-        if (fault && tid == 0) loop_abort(L, fault);
-        if (tid == 0 && L.clocks) L.clocks[g + 1] = (long long)wall_clock64();
-        for (int q = tid; q < 16 * POSE_REPLICAS; q += RING_THREADS)      // every replica, 16 granules each
-            __hip_atomic_store((unsigned long long*)loop_slot(L.slots, g + 1, q >> 4) + (q & 15), granule_of(slot_words[2 * (q & 15)], slot_words[2 * (q & 15) + 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        LOOP_STAMP(L.dbg_waves + 2 * (int)blockIdx.x + w, 4);
-#if ICP_DEBUG_TIMES
-        if (L.dbg && g == L.dbg_iter - 1 && tid == 0) L.dbg[8 * (L.dbg_waves + 2 * LOOP_RED)] = (int)(unsigned int)wall_clock64();      // when the pose of the stamped iteration went out
-#endif
-        if (L.stats && !fault) {
-            icp_iter_stats* st = L.stats + g;
-            if (tid < 16) st->pose[tid] = __uint_as_float(slot_words[tid]);
-            if (tid == 16) { st->n_src = L.n_src; st->n_valid = (int)n; st->rmse = -1.f; st->benchmark_error = -1.f; st->status = status; }
-        }
-        if (fault) return;
-        __syncthreads();                                   // slot_words / tot are rewritten by the next iteration
     }
 }
 
@@ -313,6 +325,9 @@ __device__ __forceinline__ void loop_matcher(const LoopK<DIM>& K) {
         PairOut o; bool searched, renewed;
         fused_search_post<DIM, WIDE>(kp, bv, pp, k, seeded, inc, Pm, Nm, in, bvh_lbq, tid, wave_slot, o, searched, &renewed);
         LOOP_STAMP(wave_slot, 2);
+#if ICP_DEBUG_TIMES
+        { const int ns_ = __popcll(__ballot(searched)), nr_ = __popcll(__ballot(renewed)); if (L.dbg && g == L.dbg_iter && lane == 0) { L.dbg[8 * wave_slot + 5] = ns_ | (nr_ << 8) | ((have ? 1 : 0) << 16); } }
+#endif
 #ifdef ICP_LOOP_NOHAVE
         have = false;
 #else

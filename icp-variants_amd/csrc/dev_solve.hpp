@@ -535,7 +535,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
 // hands out a line every ~2 ns, so a round of 5 790 polls takes 11 us (measured: 24-28 us per converged iteration with a single slot,
 // against 14 + 7 with one launch per iteration).  Every slot therefore exists POSE_REPLICAS times on lines far enough apart to land on
 // different channels whatever the interleave; block 0 publishes all of them, a wave polls the one its index selects.
-constexpr int POSE_REPLICAS = 64;
+#ifndef ICP_POSE_REPLICAS
+#define ICP_POSE_REPLICAS 64
+#endif
+constexpr int POSE_REPLICAS = ICP_POSE_REPLICAS;
 constexpr size_t POSE_REPLICA_STRIDE = 4096 + 128;
 __device__ __host__ __forceinline__ PoseState* loop_slot(PoseState* base, int g, int replica) {
     return (PoseState*)((char*)base + ((size_t)g * POSE_REPLICAS + (size_t)replica) * POSE_REPLICA_STRIDE);

@@ -1100,7 +1100,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
             int j = i + 1;
             while (j < iters && clouds[j] == clouds[i] && ns[j] == ns[i] && factors[j] == factors[i]) j++;
             const int nb = (ns[i] + BVH_THREADS - 1) / BVH_THREADS;
-            if (nb + LOOP_RED > cap) persist = false;      // (the reducer's two-wave blocks sit in the holes the matcher grid leaves: dev_persist.hpp)
+            if (nb + LOOP_RED + 1 > cap) persist = false;      // (the reducer's two-wave blocks sit in the holes the matcher grid leaves: dev_persist.hpp)
             if (nb > nbmax) nbmax = nb;
             segs.push_back(Seg{i, j});
             i = j;
@@ -1180,7 +1180,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
             int fused = 0;
             if ((rc = launch_match(c, q, &fused, &ml))) return rc;      // (first: nothing on the host may block between the two launches of a level)
             if (!fused) { c->err = "k_icp_loop: the matcher did not take the fused path"; return ICP_ERR_HIP; }
-            hipLaunchKernelGGL(k_icp_loop_reducer, dim3(LOOP_RED), dim3(RING_THREADS), 0, c->stream2, L);
+            hipLaunchKernelGGL(k_icp_loop_reducer, dim3(LOOP_RED + 1), dim3(RING_THREADS), 0, c->stream2, L);      // 2 x 34 fold blocks + the solver
             HIPCK(c, hipGetLastError());
         }
         HIPCK(c, hipEventRecord(c->ev_join, c->stream2));

@@ -20,9 +20,11 @@ print("iteration times (us):", np.round(a * 1000, 1).tolist())
 buf = np.zeros(n, np.int32)
 assert c.lib.icp_debug_steps(c.h, buf.ctypes.data_as(C.c_void_p), C.c_int32(n)) == 0
 nb = (n + 127) // 128; nw = nb * 2; nred = 68
-w = buf[: nw * 8].reshape(nw, 8)[:, :5].astype(np.uint32).astype(np.int64)
+wraw = buf[: nw * 8].reshape(nw, 8)
+w = wraw[:, :5].astype(np.uint32).astype(np.int64)
 r = buf[nw * 8: (nw + 2 * nred) * 8].reshape(2 * nred, 8)[:, :5].astype(np.uint32).astype(np.int64)
-t0 = int(np.uint32(buf[(nw + 2 * nred) * 8]))
+sv = buf[(nw + 2 * nred) * 8: (nw + 2 * nred) * 8 + 8].astype(np.uint32).astype(np.int64)
+t0 = int(np.uint32(buf[(nw + 2 * nred + 2) * 8]))
 it = int(os.environ.get("ICP_HIP_DBG_ITER", "-1"))
 print("iteration %d; all times in us after its pose went out" % it)
 def row(name, x):
@@ -32,4 +34,15 @@ for j, name in enumerate(["matcher: iteration top", "matcher: pose received", "m
     row(name, w[:, j])
 for j, name in enumerate(["reducer: polling starts", "reducer: fold complete", "reducer: total published"]):
     row(name, r[:, j])
-print("  solver: totals received %.2f, pose published %.2f" % ((r[0, 3] - t0) * 0.01, (r[0, 4] - t0) * 0.01))
+print("  solver: totals received %.2f, pose published %.2f" % ((sv[3] - t0) * 0.01, (sv[4] - t0) * 0.01))
+
+flags = wraw[:, 5]
+searched = flags & 0xFF; renewed = (flags >> 8) & 0xFF; had = (flags >> 16) & 1
+print("  waves: %d with lanes that searched (walk / not handed back), %d with lanes of the two-leaf tier handed back, %d came in with parked data" % ((searched > 0).sum(), (renewed > 0).sum(), had.sum()))
+late = np.argsort(w[:, 3])[-8:]
+for i in late:
+    print("   late wave %5d: searched %2d renewed %2d had %d  stamps %s" % (i, searched[i], renewed[i], had[i], np.round((w[i] - t0) * 0.01, 2)))
+for label, m in (("waves that came in with parked data", had == 1), ("waves that loaded", had == 0)):
+    if m.any():
+        x = (w[m][:, 3] - t0) * 0.01
+        print("  %-36s %5d  partial stored: mean %.2f p99 %.2f max %.2f" % (label, m.sum(), x.mean(), np.percentile(x, 99), x.max()))
