@@ -106,10 +106,12 @@ def spawn_ranks(n):
 
 class PoseGather:
     """The single collective of a batch.  Default: ncclAllGather issued from the C ABI (icp_comm_* / icp_gather_poses); the
-    128-byte unique id travels through torch.distributed, which is plumbing here.  If the C-ABI communicator cannot be created the
-    gather falls back to torch.distributed.all_gather and the JSON line says so (`pose_gather`)."""
+    128-byte unique id travels through torch.distributed, which is plumbing here.  If the C-ABI communicator cannot be created on
+    EVERY rank the run stops (all ranks, with the reason) -- a line measured with another collective is not the design BASELINE.json
+    names -- unless --allow-gather-fallback asks for torch.distributed.all_gather instead; the JSON line says which it was
+    (`pose_gather`).  device "cpu" (dry run, gloo): the same decision logic without a GPU."""
 
-    def __init__(self, world, rank, local_rank, mode, device):
+    def __init__(self, world, rank, local_rank, mode, device, allow_fallback=False):
         import torch
         import torch.distributed as dist
         self.world, self.rank, self.torch, self.dist, self.device = world, rank, torch, dist, device
@@ -117,7 +119,7 @@ class PoseGather:
         if world == 1:
             return
         self.kind = "torch.distributed.all_gather"
-        if mode == "cabi" and device != "cpu":
+        if mode == "cabi":
             from icp_amd import binding
             ok = 1; idb = bytes(binding.COMM_ID_BYTES)
             if rank == 0:
@@ -130,6 +132,7 @@ class PoseGather:
             idb = bytes(idt.cpu().numpy().tobytes())
             if not any(idb):
                 ok = 0                                                 # rank 0 could not create an id: nobody calls ncclCommInitRank
+                self.error = self.error or "rank 0 could not create the RCCL unique id"
             else:
                 try:
                     self.comm = binding.Comm(local_rank, world, rank, idb)
@@ -143,6 +146,10 @@ class PoseGather:
                 if self.comm is not None:
                     self.comm.close()
                 self.comm = None
+                if not allow_fallback:                                 # every rank gets here together (the MIN above)
+                    raise SystemExit("bench.py: rank %d: the C-ABI pose gather (icp_comm_create / ncclAllGather) is not available on every rank%s -- "
+                                     "pass --allow-gather-fallback to measure with torch.distributed.all_gather instead (the line will say so)"
+                                     % (rank, ": " + self.error if self.error else ""))
 
     def gather(self, local_poses, n_pairs):
         from icp_amd import batch
@@ -161,6 +168,10 @@ def dry_run(args, world, rank):
         dist.init_process_group(backend="gloo")
     n_pairs = args.pairs if args.pairs > 0 else world
     mine = batch.shard_pairs(n_pairs, rank, world)
+    gather_kind = None
+    if args.dry_run_cabi:                                              # the decision logic of the real run, on CPU tensors
+        g = PoseGather(world, rank, int(os.environ.get("LOCAL_RANK", "0")), "cabi", "cpu", args.allow_gather_fallback)
+        gather_kind = g.kind
 
     def fake(p):
         T = np.eye(4, dtype=np.float32); T[:3, 3] = [p, 2 * p, -p]
@@ -176,7 +187,8 @@ def dry_run(args, world, rank):
         print(json.dumps({"metric": "dry run (no device): pair sharding + pose gather only", "value": 0.0, "unit": "ICP iterations/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(1, args.steps) * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True, "config": {"workload": "dry run", "pairs": n_pairs},
-                          "gather_ok": ok, "pairs_of_rank0": mine}), flush=True)
+                          "gather_ok": ok, "pairs_of_rank0": mine, "pose_gather": gather_kind,
+                          "pairs_per_rank": [len(batch.shard_pairs(n_pairs, r, world)) for r in range(world)]}), flush=True)
     if world > 1:
         dist.destroy_process_group()
     if not ok:
@@ -209,7 +221,7 @@ def batch_mode(args, world, rank, local_rank):
     for o in opts:
         o.ctx.set_stage_timing(0)                                  # no per-stage breakdown is reported in this mode
     ctxs = [o.ctx for o in opts]
-    gather = PoseGather(world, rank, local_rank, args.gather, "cuda")
+    gather = PoseGather(world, rank, local_rank, args.gather, "cuda", args.allow_gather_fallback)
 
     def step():
         local, status, rc = binding.batch_run(ctxs, scans)
@@ -246,6 +258,7 @@ def batch_mode(args, world, rank, local_rank):
                                   "%d iterations per pair, host->device uploads and index builds inside the timed region, one pose gather per step"
                                   % (args.pairs, args.knn, args.iterations), "pairs": args.pairs, "contexts_per_gpu": n_ctx},
            "pairs_per_s": args.pairs * args.steps / elapsed, "correspondences_per_s": value * n_src, "pose_gather": gather.kind,
+           "pairs_per_rank": [len(batch.shard_pairs(args.pairs, r, world)) for r in range(world)], "max_over_ranks_step_ms": elapsed / args.steps * 1e3,
            "max_trans_err_vs_gt_m_rank0": max(errs) if errs else None}
     if gather.error:
         out["pose_gather_error"] = gather.error
@@ -291,6 +304,10 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="batch mode (configs[3]): align this many consecutive scan pairs per step, "
                     "sharded pair p -> rank p mod N, uploads and index builds INSIDE the timed region, one pose gather per step")
     ap.add_argument("--gather", choices=["cabi", "torch"], default="cabi", help="pose gather: ncclAllGather from the C ABI (default) or torch.distributed")
+    ap.add_argument("--allow-gather-fallback", action="store_true", help="if the C-ABI communicator cannot be created on every rank, gather with "
+                    "torch.distributed.all_gather instead of stopping (the line then says so in `pose_gather`)")
+    ap.add_argument("--dry-run-cabi", action="store_true", help="with --dry-run: also go through the C-ABI communicator set-up (no GPU: it cannot succeed; tests the "
+                    "all-ranks-take-the-same-path logic of the fallback)")
     ap.add_argument("--no-extras", action="store_true", help="skip the legs outside the timed region (per-iteration records, the always-walk comparison run): "
                     "for profiling, so that a kernel trace holds the launches of the warm-up and timed steps only")
     ap.add_argument("--dry-run", action="store_true", help="no device: rehearse the N-rank sharding + pose gather on CPU (gloo)")
@@ -336,7 +353,7 @@ def main():
     ctx.set_target(pair["tgt_pts"], pair["tgt_nrm"], None)              # resident in HBM before the timed region
     ctx.set_source(pair["src_pts"], pair["src_nrm"], None)
     eye = binding.pose_to_c(np.eye(4, dtype=np.float32))
-    gather = PoseGather(world, rank, local_rank, args.gather, "cuda")
+    gather = PoseGather(world, rank, local_rank, args.gather, "cuda", args.allow_gather_fallback)
 
     # optional extra resident pairs on their own contexts / streams / host threads (ctypes releases the GIL)
     R = max(1, args.resident_pairs)
@@ -460,6 +477,7 @@ def main():
                              "every %s iteration of the timed region (offset rotating per step)" % ("" if args.stage_timing == 1 else "%d-th" % args.stage_timing)},
         "pose_error_vs_gt": {"rot_rad": rot_err, "trans_m": trans_err},
         "pose_gather": gather.kind,
+        "pairs_per_rank": [R] * world, "max_over_ranks_step_ms": elapsed / args.steps * 1e3,
     }
     import ctypes as _C
     _a, _b = _C.c_int32(0), _C.c_int32(0)

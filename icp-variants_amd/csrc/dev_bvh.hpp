@@ -13,9 +13,9 @@
 //           packed-f32 math, filled bottom-up; the 1-NN walk uses 4-wide nodes derived from them (two levels collapsed)
 //           and 32-byte target records in leaf order.
 //   query : one lane = one query, depth-first "nearest child first".  A node is skipped only if its box lower bound
-//           exceeds the running best; the bound uses the same operation sequence as the point distance, so by
-//           monotonicity of IEEE rounding fl(d2(point)) >= fl(lb) for every point in the box (a 2e-5 relative margin is
-//           kept on top).  Equal distances resolve to the lowest original index, exactly like the strict-< scan
+//           exceeds the running best times ICP_PRUNE_SLACK (1.001, see there); the bound uses the same operation sequence as the
+//           point distance, so by monotonicity of IEEE rounding fl(d2(point)) >= fl(lb) for every point in the box -- any factor
+//           >= 1 keeps the search exact.  Equal distances resolve to the lowest original index, exactly like the strict-< scan
 //           (NearestNeighbor.h:87).
 #ifndef ICP_ISEL_NATURAL
 #define ICP_ISEL_NATURAL 0        // 1: the natural spellings of two expressions in k_bvh_block_levels that crash the ROCm 7.2 gfx950 instruction selector
@@ -628,7 +628,7 @@ template <int DIM, class MaskT>
 __device__ __forceinline__ void quad_run(const BvhViewT<DIM>& bv, const QueryPt<DIM>& qp, QuadStateT<MaskT>& st,
                                          float& best, int& bi, int& bpos, float& b2, int& l2, float& b3, float& minlb, int& dbg_nodes, int& dbg_leaves) {
     const int Lq = bv.Lq;
-    // A box is skipped when its lower bound exceeds thr = best * (1 + 2e-5) (clamped so that the +inf bound of an empty box is
+    // A box is skipped when its lower bound exceeds thr = best * ICP_PRUNE_SLACK (clamped so that the +inf bound of an empty box is
     // always skipped): that implies bound > best with margin, one multiply per change of `best` instead of one per box test.
     float thr = fminf(best * ICP_PRUNE_SLACK, FLT_MAX);
     // smallest skipped bound, kept as its bit pattern: bounds are >= +0, so unsigned order is value order and the integer minimum
@@ -749,9 +749,20 @@ __device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, cons
 // record in LDS: (distance, index) by a 64-bit atomic minimum (= the lexicographic minimum the lone walk computes), the bounds
 // on all other points by 32-bit atomic minima of their bit patterns.  Every subtree is still searched by exactly one lane against
 // a bound that is at least the final distance, so the result is the same exact neighbour; only the bounds used by NEXT iteration's
-// verify test may differ (conservatively).  A query whose walk was shared gets no out-of-leaf bound (second tier off for it).
-// Rows of the wave's LDS slots: 0 key, 1 (others, skipped bound), 2 (out-of-leaf, position), 3-5 and 7-9 the lanes' own results,
-// query and normal parked meanwhile (so that a helper needs no registers of its own for them), 6 the donors' lane numbers.
+// verify tests may differ from the lone walk's (never larger than what is true).
+//   What the merge keeps per owner, and why both verify tiers may use it (the invariant of the fold below): key = the minimum
+//   (distance, index) over everything any searcher evaluated = the neighbour; key2 = the minimum (distance, leaf) over the runner-up
+//   entries -- a searcher's own (b2, l2), its winner when that lost against key, a winner it dethroned; `rest` = a lower bound on every
+//   evaluated or skipped target that is NEITHER the neighbour NOR covered by key2, where "covered" means: lies in key2's leaf and is at
+//   least key2's distance away.  Every time an entry loses against another one it goes into `rest` unless it lives in the winning entry's
+//   leaf (then that entry covers it); every skipped box goes into the separate skipped-bound minimum.  Hence, for the finished search:
+//     lb_others = min(key2.distance, rest, skipped)  bounds every target but the neighbour              (first tier),
+//     lb3       = min(rest, skipped)                 bounds every target outside the neighbour's leaf AND key2's leaf, plus possibly some
+//                                                    inside them -- a smaller, still valid bound          (second tier, l2 = key2's leaf).
+//   (A winner dethroned during the merge has no leaf on record and goes straight to `rest`: conservative for that one iteration.)
+// Rows of the wave's LDS slots: 0 key, 1 key2 (runner-up entry), 2 (rest, position of the winner), 3-5 and 7-9 the lanes' own results,
+// query and normal parked meanwhile (so that a helper needs no registers of its own for them), 6 the donors' lane numbers (first half)
+// and the smallest skipped box bound per owner (second half).
 template <int DIM, int NT, class MaskT>
 __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* p, float* keep3, bool need_walk, float& best, int& bi, int& bpos, float& lb_others, float& lb3, int& l2o,
                                                 uint2* __restrict__ lbq, int tid) {

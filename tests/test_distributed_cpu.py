@@ -90,3 +90,23 @@ def test_cabi_shard_rule_matches_python():
         for r in range(world):
             assert binding.pairs_of_rank(n_pairs, r, world) == len(batch.shard_pairs(n_pairs, r, world))
         assert [binding.pair_owner(p, world) for p in range(n_pairs)] == [p % world for p in range(n_pairs)]
+
+
+def test_gather_fallback_is_loud_and_taken_by_all_ranks_together():
+    """bench.py's pose-gather decision with the C-ABI communicator unavailable (no GPU here; and rank 0 cannot even create the RCCL id:
+    ICP_HIP_RCCL_LIB points nowhere): without --allow-gather-fallback EVERY rank stops with the reason (exit != 0, no JSON line);
+    with it all ranks take torch.distributed.all_gather together and the line says so."""
+    import json, subprocess, sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ICP_HIP_RCCL_LIB"] = "/nonexistent/librccl.so.1"
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--dry-run-cabi", "--steps", "1"]
+    bad = subprocess.run(base, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert bad.returncode != 0
+    assert not [ln for ln in bad.stdout.decode().splitlines() if ln.lstrip().startswith("{")]
+    err = bad.stderr.decode()
+    assert "--allow-gather-fallback" in err and "rank 0" in err and "rank 1" in err          # both ranks stopped, each saying why
+    ok = subprocess.run(base + ["--allow-gather-fallback"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert ok.returncode == 0, ok.stderr.decode()[-2000:]
+    rec = json.loads([ln for ln in ok.stdout.decode().splitlines() if ln.lstrip().startswith("{")][0])
+    assert rec["pose_gather"] == "torch.distributed.all_gather" and rec["gather_ok"] is True and rec["pairs_per_rank"] == [1, 1]
