@@ -292,7 +292,7 @@ def main():
     ap.add_argument("--n-beam", type=int, default=1077)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-iteration", action="store_true", help="add the matcher's average device ms per iteration index to per_regime_ms")
-    ap.add_argument("--stage-timing", type=int, default=10, help="bracket every Nth ICP iteration of the timed region with HIP events (offset rotates "
+    ap.add_argument("--stage-timing", type=int, default=17, help="bracket every Nth ICP iteration of the timed region with HIP events (offset rotates "
                     "from step to step: after N steps every iteration index has been timed once); 1 = every iteration, as the reference's "
                     "TimeMeasure does (costs ~10 %% of an iteration); an event bracket costs ~3 us of stream time")
     ap.add_argument("--no-incremental", action="store_true", help="always walk the BVH (disable the exact verify-and-skip of converged queries)")

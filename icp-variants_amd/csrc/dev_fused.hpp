@@ -262,7 +262,8 @@ __device__ __forceinline__ void fused_block_epilogue(const KnnParams& kp, const 
 
 // One launch per iteration.  MERGED: the launch of iteration i carries the reducer of iteration i - 1 in its first rp.n_red blocks and
 // every matcher block waits for the pose they publish (dev_solve.hpp, "the ring form") -- AFTER it has issued the loads that do not
-// need the pose.
+// need the pose.  (Measured and dropped: holding the matcher's burst back by 3 / 6 / 12 us so that the reducer's loads go first -- 33.5 k /
+// 31.6 k / 26.0 k iterations/s against 33.5 k without -- and loading only after the pose has arrived: 32.8 k.)
 template <int DIM, bool WIDE, bool MERGED>      // WIDE: trees deeper than 8 levels of 4-wide nodes (> 524 288 targets) keep 64 pending bits per lane
 __device__ __forceinline__ void fused_matcher_body(const KnnParams& kp, const BvhViewT<DIM>& bv, const int* __restrict__ qorder, const PostParams& pp, const RingParams& rp) {
     extern __shared__ uint2 bvh_lbq[];                    // [ICP_SHARE_ROWS][BVH_THREADS]: the shared walk's records; reused by the reduction

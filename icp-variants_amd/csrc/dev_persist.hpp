@@ -42,6 +42,7 @@ struct LoopParams {
     unsigned long long* totals;        // [run iterations][TOTALS_ROW] totals ring: three granules per sum (see loop_reducer)
     unsigned long long* pring;         // [PRING_DEPTH][NSUM_USED][nb] block partials of iteration g in slot g % PRING_DEPTH
     int nb;                            // matcher blocks
+    int wave_presleep_eighths;         // a matcher wave sleeps through this many eighths of the last iteration's length (pose to pose) before it polls for the next pose
     int presleep_eighths;              // the reducer sleeps through this many eighths of the last iteration's length before its first poll
     int dictated;                      // 1: every pose slot is filled up front and nobody reduces (icp_match_seeded)
     icp_iter_stats* stats;             // [run iterations] records
@@ -49,6 +50,7 @@ struct LoopParams {
     int* abort_word;                   // != 0: leave
     int record_last;                   // 1: the LAST iteration writes its Match records / distances (pp.matches / kp.d2_out)
     int* dbg; int dbg_iter, dbg_waves; // development builds (ICP_DEBUG_TIMES): phase stamps of iteration dbg_iter: matcher waves at dbg[8 * wave], reducer blocks behind them
+    PoseState* final_out; int final_g; // when the solver publishes slot final_g it also leaves that pose state here (beside the records: ONE copy back)
     long long* clocks;                 // [run iterations + 1] the 100 MHz clock when pose slot g became available (block 0; nullptr: not kept)
 };
 
@@ -127,23 +129,18 @@ __device__ __forceinline__ void loop_solver(const LoopParams& L) {
         else if (n > 0) { npose = p2plane_lanes_core(tot + SUM_M, pin->pose); if (!npose) fault = 2; }      // (uniform)
         else status = ICP_ERR_NO_CORRESPONDENCES;          // the pose stays (ICPOptimizer.h:668,680: the reference would hang in ASSERT)
         if (tid < 16) slot_words[tid] = __float_as_uint(npose ? npose[tid] : pin->pose[tid]);
-        if (tid == 32) {
-            float nm[9];
-            if (npose) normal_matrix_from_pose(npose, nm); else for (int q = 0; q < 9; q++) nm[q] = pin->nmat[q];
-            for (int q = 0; q < 9; q++) slot_words[16 + q] = __float_as_uint(nm[q]);
+        if (tid >= 32 && tid < 41) slot_words[16 + (tid - 32)] = __float_as_uint(npose ? normal_matrix_entry(npose, tid - 32) : pin->nmat[tid - 32]);      // one entry per lane
+        if (tid >= 41 && tid < 47) {
+            const int k = tid - 41;
+            slot_words[25 + k] = __float_as_uint(n > 0 ? (float)(tot[(k < 3 ? SUM_S : SUM_D - 3) + k] / n) : 0.f);
         }
-        if (tid == 33) {
-            for (int k = 0; k < 3; k++) {
-                slot_words[25 + k] = __float_as_uint(n > 0 ? (float)(tot[SUM_S + k] / n) : 0.f);
-                slot_words[28 + k] = __float_as_uint(n > 0 ? (float)(tot[SUM_D + k] / n) : 0.f);
-            }
-            slot_words[31] = (unsigned int)fault;
-        }
+        if (tid == 47) slot_words[31] = (unsigned int)fault;
         __syncthreads();
         if (fault && tid == 0) loop_abort(L, fault);
         if (tid == 0 && L.clocks) L.clocks[g + 1] = (long long)wall_clock64();
         for (int q = tid; q < 16 * POSE_REPLICAS; q += WAVE)          // every replica, 16 granules each
             __hip_atomic_store((unsigned long long*)loop_slot(L.slots, g + 1, q >> 4) + (q & 15), granule_of(slot_words[2 * (q & 15)], slot_words[2 * (q & 15) + 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (L.final_out && g + 1 == L.final_g && tid < 32) ((unsigned int*)L.final_out)[tid] = slot_words[tid];
         LOOP_STAMP(L.dbg_waves + 2 * LOOP_RED, 4);
 #if ICP_DEBUG_TIMES
         if (L.dbg && g == L.dbg_iter - 1 && tid == 0) L.dbg[8 * (L.dbg_waves + 2 * LOOP_RED + 2)] = (int)(unsigned int)wall_clock64();      // when the pose of the stamped iteration went out
@@ -293,6 +290,8 @@ __device__ __forceinline__ void loop_matcher(const LoopK<DIM>& K) {
     const int k_fixed = t < K.n ? t : -1;                // (sorted levels: the query index is the position)
     int q0_kept = -1;                                      // (the one carried value that stays in a register)
     bool have = false;
+    unsigned long long renew_mask = 0ull;                  // lanes whose query took the two-leaf tier last time: it will again (it sits between two targets)
+    int t_pose = 0, period = 0;                            // 100 MHz clock (low word) when the last pose arrived, and the time between the last two arrivals
     for (int it = 0; it < L.iters; it++) {
         int k = k_fixed, tid = tid_fixed, S = K.src_stride, Q = K.q_cap;
         asm volatile("" : "+v"(k), "+v"(tid), "+s"(S), "+s"(Q));     // see LoopK
@@ -319,8 +318,26 @@ __device__ __forceinline__ void loop_matcher(const LoopK<DIM>& K) {
             if (DIM == 3 && inc) { loop_park<DIM>(bvh_lbq, tid, in); q0_kept = in.q0; }      // (a walk of this wave overwrites the rows: then nobody reads them back)
 #endif
         } else { loop_unpark<DIM>(bvh_lbq, tid, in); in.q0 = q0_kept; }
+        // A query of the two-leaf tier pays three dependent trips to memory behind the pose (second-tier bound -> two leaves), and with it
+        // its wave and the wave it shares the block barrier with: the last ones of every converged iteration by 5 us (tools/dev_loop_times.py).
+        // The same lines can be asked for NOW, while the wave waits for the pose anyway: afterwards they are cache hits.
+        if (have && ((renew_mask >> lane) & 1ull) && kp.qstate2) {
+            const float2 st2 = kp.qstate2[k];
+            const int l2 = __float_as_int(st2.y);
+            int touch = *(const int*)(bv.leaves + (in.q0 >> 3));
+            if (l2 >= 0) touch |= *(const int*)(bv.leaves + l2);
+            asm volatile("" :: "v"(touch));
+        }
+        // A wave that is done long before the slowest walk of the launch would poll all the while (the early iterations: 5 000 waves, 100 us);
+        // it sleeps through most of what the last iteration took instead -- iterations get shorter slowly, and a wave that oversleeps costs
+        // only itself -- and polls from there.
+        if (period > 0 && L.wave_presleep_eighths > 0) {
+            const int until = t_pose + ((period >> 3) * L.wave_presleep_eighths);
+            while ((int)((unsigned int)wall_clock64() - (unsigned int)until) < 0) __builtin_amdgcn_s_sleep(16);
+        }
         float Pm[16], Nm[9];
         if (!loop_wait_pose(L, loop_slot(L.slots, g, L.dictated ? 0 : (int)((blockIdx.x * 2u + (unsigned int)(tid >> 6)) % (unsigned int)POSE_REPLICAS)), lane, Pm, Nm)) return;
+        { const int now = (int)(unsigned int)wall_clock64(); if (it > 0) period = now - t_pose; t_pose = now; }
         LOOP_STAMP(wave_slot, 1);
         PairOut o; bool searched, renewed;
         fused_search_post<DIM, WIDE>(kp, bv, pp, k, seeded, inc, Pm, Nm, in, bvh_lbq, tid, wave_slot, o, searched, &renewed);
@@ -334,6 +351,7 @@ __device__ __forceinline__ void loop_matcher(const LoopK<DIM>& K) {
         // (a query of the two-leaf tier -- a handful sit between two targets and take it in EVERY iteration -- gives its new state back: parked
         //  again, the wave keeps everything; reloading it all from memory made those few waves the last of every converged iteration by 6 us)
         have = DIM == 3 && inc && !__any(searched);
+        renew_mask = __ballot(renewed);
         if (have && renewed) { loop_park<DIM>(bvh_lbq, tid, in); q0_kept = in.q0; }
 #endif
         unsigned long long* prow = L.pring + (size_t)(it % PRING_DEPTH) * NSUM_USED * L.nb;

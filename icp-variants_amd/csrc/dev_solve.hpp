@@ -225,6 +225,23 @@ __device__ __host__ inline void normal_matrix_from_pose(const float* pose, float
     N[6] = (float)(c20 / det); N[7] = (float)(c21 / det); N[8] = (float)(c22 / det);
 }
 
+// one entry of the same matrix (entry e = 3 row + column): the same operations on the same values as normal_matrix_from_pose, so the
+// nine lanes that each compute one give the nine floats it gives
+__device__ inline float normal_matrix_entry(const float* pose, int e) {
+    const double a = pose[0], b = pose[4], c = pose[8];
+    const double d = pose[1], e_ = pose[5], f = pose[9];
+    const double g = pose[2], h = pose[6], i = pose[10];
+    const double c00 = e_ * i - f * h, c01 = f * g - d * i, c02 = d * h - e_ * g;
+    const double det = (a * c00 + b * c01) + c * c02;
+    double cof;
+    switch (e) {
+        case 0: cof = c00; break;  case 1: cof = c01; break;  case 2: cof = c02; break;
+        case 3: cof = c * h - b * i; break;  case 4: cof = a * i - c * g; break;  case 5: cof = b * g - a * h; break;
+        case 6: cof = b * f - c * e_; break;  case 7: cof = c * d - a * f; break;  default: cof = a * e_ - b * d; break;
+    }
+    return (float)(cof / det);
+}
+
 struct SolveParams {
     const double* partials; int nblocks;   // [NSUM][nblocks]
     double* totals; unsigned* ticket;      // NSUM reduced sums; arrival counter (0 between launches)
@@ -536,7 +553,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_reduce_solve(const SolveParam
 // against 14 + 7 with one launch per iteration).  Every slot therefore exists POSE_REPLICAS times on lines far enough apart to land on
 // different channels whatever the interleave; block 0 publishes all of them, a wave polls the one its index selects.
 #ifndef ICP_POSE_REPLICAS
-#define ICP_POSE_REPLICAS 64
+#define ICP_POSE_REPLICAS 16
 #endif
 constexpr int POSE_REPLICAS = ICP_POSE_REPLICAS;
 constexpr size_t POSE_REPLICA_STRIDE = 4096 + 128;
@@ -548,10 +565,18 @@ __device__ __host__ __forceinline__ PoseState* loop_slot(PoseState* base, int g,
 #else
 #define LOOP_STAMP(slot, j)
 #endif
-// the incoming pose of a run into every replica of slot 0 (one launch instead of POSE_REPLICAS copies)
-__global__ void k_pose_replicas(const PoseState* __restrict__ src, PoseState* slot0) {
+// One launch in front of a run of the merged / one-launch loop: slot 0 = the incoming pose in every replica, every other slot's granules
+// and the totals rows "empty", the fault word and the clocks zero.  (Only the 128 bytes of a replica that are ever read are touched --
+// the replicas sit 4 KB apart.)
+__global__ void k_run_init(const PoseState* __restrict__ src, PoseState* slots, int n_slots, unsigned long long* totals, int n_totals, int* zero_words, int n_zero) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < 32 * POSE_REPLICAS) ((unsigned int*)loop_slot(slot0, 0, t >> 5))[t & 31] = ((const unsigned int*)src)[t & 31];
+    const int n_slot_granules = n_slots * POSE_REPLICAS * 16;
+    if (t < n_slot_granules) {
+        const int g = t / (POSE_REPLICAS * 16), r = (t / 16) % POSE_REPLICAS, q = t & 15;
+        unsigned long long* dst = (unsigned long long*)loop_slot(slots, g, r) + q;
+        *dst = g == 0 ? ((const unsigned long long*)src)[q] : ~0ull;
+    } else if (t < n_slot_granules + n_totals) totals[t - n_slot_granules] = ~0ull;
+    else if (t < n_slot_granules + n_totals + n_zero) zero_words[t - n_slot_granules - n_totals] = 0;
 }
 constexpr unsigned long long GRANULE_EMPTY = ~0ull;
 #ifndef ICP_RING_SLEEP
@@ -563,6 +588,7 @@ struct RingParams {
     const PoseState* ps_in;                        // the pose that iteration searched at (replica 0 of its slot): complete since the previous launch
     PoseState* ps_out;                             // slot to publish, POSE_REPLICAS copies of it (loop_slot): the pose the matcher blocks of THIS launch wait for
     icp_iter_stats* stats; int n_src;              // record of the reduced iteration
+    PoseState* final_out;                          // the closing launch of a run: the final pose state also goes here (beside the records: ONE copy back); else nullptr
     int* run_fault;                                // raised by any waiter that ran out of polls
     int n_red;                                     // reducer blocks in front of this grid: 0 (first launch of a run) or NSUM_USED
 };
@@ -582,7 +608,8 @@ __device__ __forceinline__ void ring_reduce_solve(const RingParams& rp) {
     __shared__ int give_up;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, a = blockIdx.x;
     if (a == 0 && rp.ps_in->fault) {                      // the chain was cut further up: pass it on, touch nothing else
-        { const unsigned int* src = (const unsigned int*)rp.ps_in; for (int q = tid; q < 16 * POSE_REPLICAS; q += RING_THREADS) __hip_atomic_store((unsigned long long*)loop_slot(rp.ps_out, 0, q >> 4) + (q & 15), granule_of(src[2 * (q & 15)], src[2 * (q & 15) + 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        { const unsigned int* src = (const unsigned int*)rp.ps_in; for (int q = tid; q < 16 * POSE_REPLICAS; q += RING_THREADS) __hip_atomic_store((unsigned long long*)loop_slot(rp.ps_out, 0, q >> 4) + (q & 15), granule_of(src[2 * (q & 15)], src[2 * (q & 15) + 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (rp.final_out && tid < 32) ((unsigned int*)rp.final_out)[tid] = src[tid]; }
         return;
     }
     {
@@ -655,6 +682,7 @@ __device__ __forceinline__ void ring_reduce_solve(const RingParams& rp) {
     __syncthreads();
     for (int q = tid; q < 16 * POSE_REPLICAS; q += RING_THREADS)      // every replica of the slot, 16 granules each
         __hip_atomic_store((unsigned long long*)loop_slot(rp.ps_out, 0, q >> 4) + (q & 15), granule_of(slot_words[2 * (q & 15)], slot_words[2 * (q & 15) + 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (rp.final_out && tid < 32) ((unsigned int*)rp.final_out)[tid] = slot_words[tid];
     if (rp.stats && !fault) {                             // the record of the reduced iteration (read by the host after the run)
         if (tid < 16) rp.stats->pose[tid] = __uint_as_float(slot_words[tid]);
         if (tid == 16) { rp.stats->n_src = rp.n_src; rp.stats->n_valid = (int)n; rp.stats->rmse = -1.f; rp.stats->benchmark_error = -1.f; rp.stats->status = status; }

@@ -81,6 +81,7 @@ struct icp_ctx {
     bool trace = false;                  // ICP_HIP_TRACE=1: per-iteration stage times on stderr
     bool fuse_post = true;               // BVH matcher runs weight / reject / accumulate as its epilogue (ICP_HIP_FUSE_POST=0 disables)
     bool merge_loop = true;              // point-to-plane loop through the fused BVH matcher: reduce + solve ride in front of the next matcher launch (ICP_HIP_MERGE=0: separate k_reduce_solve launches)
+    int loop_from = 0;                   // k_icp_loop takes over at this iteration of a run; the ones before it run one (merged) launch each (ICP_HIP_LOOP_FROM)
     bool persist_loop = false;           // ICP_HIP_PERSIST=1 (experimental, measured slower than the merged loop so far: DESIGN.md): when the whole grid fits the device at once, the loop of a resolution level as ONE launch (k_icp_loop; ICP_HIP_PERSIST=0 disables)
     bool shared_gpu = false;             // other contexts work on this device at the same time (icp_batch_run with several contexts): one launch per iteration
     int loop_runs = 0;                   // runs that took k_icp_loop (icp_debug_counters)
@@ -746,6 +747,7 @@ int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out) {
     { const char* e = getenv("ICP_HIP_TIER2"); if (e && e[0] == '0') c->tier2 = false; }
     { const char* e = getenv("ICP_HIP_MERGE"); if (e && e[0] == '0') c->merge_loop = false; }
     { const char* e = getenv("ICP_HIP_PERSIST"); if (e) c->persist_loop = e[0] == '1'; }
+    { const char* e = getenv("ICP_HIP_LOOP_FROM"); if (e) c->loop_from = atoi(e); }
     { const char* e = getenv("ICP_HIP_PRESORT"); if (e && e[0] == '0') c->presort = false; }
     { const char* e = getenv("ICP_HIP_BLOCK_LEVELS"); if (e && e[0] == '0') c->block_levels = false; }
     { const char* e = getenv("ICP_HIP_TRACE"); if (e && e[0] == '1') c->trace = true; }
@@ -1020,7 +1022,10 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     if ((rc = ensure_pinned(c, pin_pose + 512 + (size_t)(iters + 1) * 8))) return rc;
     float pose_in[16]; memcpy(pose_in, pose_inout, 64);        // the record of an empty iteration 0 carries the incoming pose
     if ((rc = write_pose(c, pose_inout))) return rc;
-    if ((rc = ensure(c, c->stats, (size_t)iters * sizeof(icp_iter_stats)))) return rc;
+    // the records of the run, and behind them (merged / one-launch loops) the final pose state, the fault word and the device clocks:
+    // ONE block, ONE copy back -- laid out like the page-locked block it lands in (pin_stats .. pin_pose .. + 128 .. + 192)
+    const size_t stats_pad = pin_pose - pin_stats;
+    if ((rc = ensure(c, c->stats, stats_pad + 192 + (size_t)(iters + 1) * 8))) return rc;
     // (every record of an iteration with work is written in full by k_reduce_solve; empty iterations are filled in on the host)
     if ((rc = ensure_events(c, (size_t)iters * 4 + 2))) return rc;
     // resolve selections up front (uploads) so the loop itself is launch-only
@@ -1068,19 +1073,6 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     bool merged = c->merge_loop && !single && iters >= 2 && sorted_levels && c->fuse_post && p.metric == ICP_METRIC_POINT_TO_PLANE && !rmse && !fontana;
     for (int i = 0; merged && i < iters; i++) if (ns[i] <= 0) merged = false;
     PoseState* slots = nullptr; unsigned long long* trows = nullptr; int* run_fault = nullptr;
-    if (merged) {
-        static_assert(sizeof(PoseState) == 128, "a pose slot is 16 granules");
-        const size_t slot_bytes = (size_t)(iters + 1) * POSE_REPLICAS * POSE_REPLICA_STRIDE, tot_bytes = (size_t)iters * NSUM * 8;
-        int nbmax = POST_BLOCKS;
-        for (int i = 0; i < iters; i++) { const int nb = (ns[i] + BVH_THREADS - 1) / BVH_THREADS; if (nb > nbmax) nbmax = nb; }
-        if ((rc = ensure(c, c->ring, slot_bytes + tot_bytes + 64))) return rc;
-        if ((rc = ensure(c, c->partials, (size_t)nbmax * NSUM * 8))) return rc;
-        if ((rc = ensure(c, c->partials2, (size_t)nbmax * NSUM * 8))) return rc;
-        slots = c->ring.as<PoseState>(); trows = (unsigned long long*)(c->ring.as<char>() + slot_bytes); run_fault = (int*)(c->ring.as<char>() + slot_bytes + tot_bytes);
-        HIPCK(c, hipMemsetAsync(c->ring.p, 0xFF, slot_bytes + tot_bytes, c->stream));
-        HIPCK(c, hipMemsetAsync(run_fault, 0, 64, c->stream));
-        hipLaunchKernelGGL(k_pose_replicas, dim3((32 * POSE_REPLICAS + 255) / 256), dim3(256), 0, c->stream, c->ps.as<PoseState>(), slots);      // slot 0 = the incoming pose (write_pose above), every replica
-    }
     // k_icp_loop (dev_persist.hpp): all iterations of a resolution level in ONE launch, the waves resident from iteration to iteration.
     // Needs the whole grid on the device at once (its blocks wait for each other) and the device to itself: checked against the kernel's
     // occupancy; a context marked shared, or one that finds another context's loop in flight, runs one launch per iteration instead.
@@ -1089,6 +1081,10 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     LoopToken token;
     bool persist = merged && c->persist_loop && !c->shared_gpu;
     long long* d_clocks = nullptr;
+    // The first loop_from iterations -- every query walks, a launch lasts 50-150 us, and the walk is ~5 % slower in k_icp_loop (it pays for
+    // its residency with a few spilled registers) -- run one launch per iteration in the merged form; k_icp_loop takes over from there.
+    int loop_from = c->loop_from < 0 ? 0 : c->loop_from;
+    if (persist && loop_from >= iters) persist = false;
     if (persist) {
         Bvh& tb = p.color_icp ? c->bvh6 : c->bvh;
         int cap = -1;
@@ -1096,7 +1092,8 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
         else if (p.color_icp) { if ((rc = tb.Lq <= 8 ? loop_capacity_of<6, false>(c, &cap) : loop_capacity_of<6, true>(c, &cap))) return rc; }
         else { if ((rc = tb.Lq <= 8 ? loop_capacity_of<3, false>(c, &cap) : loop_capacity_of<3, true>(c, &cap))) return rc; }
         int nbmax = 1;
-        for (int i = 0; persist && i < iters; ) {
+        for (int i = 0; i < iters; i++) { const int nb = (ns[i] + BVH_THREADS - 1) / BVH_THREADS; if (nb > nbmax) nbmax = nb; }
+        for (int i = loop_from; persist && i < iters; ) {
             int j = i + 1;
             while (j < iters && clouds[j] == clouds[i] && ns[j] == ns[i] && factors[j] == factors[i]) j++;
             const int nb = (ns[i] + BVH_THREADS - 1) / BVH_THREADS;
@@ -1112,7 +1109,8 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
             { int nmax = 1; for (int i = 0; i < iters; i++) if (ns[i] > nmax) nmax = ns[i];
               if ((rc = ensure_match_buffers(c, nmax))) return rc;
               if ((rc = ensure_qpack(c, nmax))) return rc;
-              if ((rc = ensure(c, c->partials, (size_t)(nbmax > POST_BLOCKS ? nbmax : POST_BLOCKS) * NSUM * 8))) return rc; }
+              if ((rc = ensure(c, c->partials, (size_t)(nbmax > POST_BLOCKS ? nbmax : POST_BLOCKS) * NSUM * 8))) return rc;
+              if ((rc = ensure(c, c->partials2, (size_t)(nbmax > POST_BLOCKS ? nbmax : POST_BLOCKS) * NSUM * 8))) return rc; }
             size_t pring_granules = 0;
             for (const Seg& sg : segs) pring_granules += (size_t)PRING_DEPTH * NSUM_USED * ((ns[sg.i0] + BVH_THREADS - 1) / BVH_THREADS);
             if ((rc = ensure(c, c->pring, pring_granules * 8))) return rc;
@@ -1122,15 +1120,26 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
                 HIPCK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
                 HIPCK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
             }
-            // its own rings: [pose slots x POSE_REPLICAS | totals | fault word | clocks]
-            const size_t slot_bytes = (size_t)(iters + 1) * POSE_REPLICAS * POSE_REPLICA_STRIDE, tot_bytes = (size_t)iters * TOTALS_ROW * 8, clk_bytes = (size_t)(iters + 1) * 8;
-            if ((rc = ensure(c, c->ring, slot_bytes + tot_bytes + 64 + clk_bytes))) return rc;
-            slots = c->ring.as<PoseState>(); trows = (unsigned long long*)(c->ring.as<char>() + slot_bytes); run_fault = (int*)(c->ring.as<char>() + slot_bytes + tot_bytes);
-            d_clocks = (long long*)(c->ring.as<char>() + slot_bytes + tot_bytes + 64);
-            HIPCK(c, hipMemsetAsync(c->ring.p, 0xFF, slot_bytes + tot_bytes, c->stream));
-            HIPCK(c, hipMemsetAsync(run_fault, 0, 64 + clk_bytes, c->stream));
-            hipLaunchKernelGGL(k_pose_replicas, dim3((32 * POSE_REPLICAS + 255) / 256), dim3(256), 0, c->stream, c->ps.as<PoseState>(), slots);      // slot 0 = the incoming pose, every replica
+            // its rings: [pose slots x POSE_REPLICAS | totals]; fault word and clocks sit behind the records (see above)
+            const size_t slot_bytes = (size_t)(iters + 1) * POSE_REPLICAS * POSE_REPLICA_STRIDE, tot_bytes = (size_t)iters * TOTALS_ROW * 8;
+            if ((rc = ensure(c, c->ring, slot_bytes + tot_bytes))) return rc;
+            slots = c->ring.as<PoseState>(); trows = (unsigned long long*)(c->ring.as<char>() + slot_bytes);
+            run_fault = (int*)(c->stats.as<char>() + stats_pad + 128); d_clocks = (long long*)(c->stats.as<char>() + stats_pad + 192);
+            const int n_init = (iters + 1) * POSE_REPLICAS * 16 + iters * TOTALS_ROW + 16 + (iters + 1) * 2;
+            hipLaunchKernelGGL(k_run_init, dim3((n_init + 255) / 256), dim3(256), 0, c->stream, c->ps.as<PoseState>(), slots, iters + 1, trows, iters * TOTALS_ROW, run_fault, 16 + (iters + 1) * 2);
         }
+    }
+    if (merged && !persist) {
+        static_assert(sizeof(PoseState) == 128, "a pose slot is 16 granules");
+        const size_t slot_bytes = (size_t)(iters + 1) * POSE_REPLICAS * POSE_REPLICA_STRIDE, tot_bytes = (size_t)iters * NSUM * 8;
+        int nbmax = POST_BLOCKS;
+        for (int i = 0; i < iters; i++) { const int nb = (ns[i] + BVH_THREADS - 1) / BVH_THREADS; if (nb > nbmax) nbmax = nb; }
+        if ((rc = ensure(c, c->ring, slot_bytes + tot_bytes))) return rc;
+        if ((rc = ensure(c, c->partials, (size_t)nbmax * NSUM * 8))) return rc;
+        if ((rc = ensure(c, c->partials2, (size_t)nbmax * NSUM * 8))) return rc;
+        slots = c->ring.as<PoseState>(); trows = (unsigned long long*)(c->ring.as<char>() + slot_bytes); run_fault = (int*)(c->stats.as<char>() + stats_pad + 128);
+        const int n_init = (iters + 1) * POSE_REPLICAS * 16 + iters * NSUM + 16;
+        hipLaunchKernelGGL(k_run_init, dim3((n_init + 255) / 256), dim3(256), 0, c->stream, c->ps.as<PoseState>(), slots, iters + 1, trows, iters * NSUM, run_fault, 16);      // (both rings are reset: nothing survives an aborted run)
     }
     // Stage timing (TimeMeasure.h:20-26).  A HIP event costs ~4 us of stream time, two to three per iteration are ~10 % of a
     // 0.07 ms iteration: mode N > 1 brackets only every Nth iteration (offset rotating from run to run) and scales the sums.
@@ -1143,7 +1152,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     for (int i = 0; i < iters; i++) sampled[i] = tmode == 1 || (tmode > 1 && (i + (int)(c->timing_phase % (unsigned)tmode)) % tmode == 0);
     c->timing_phase++;
     auto E = [&](int i, int k) { return c->events[(size_t)2 + 4 * i + k]; };
-    auto end_event = [&](int i) { return (merged && i < iters - 1) ? E(i, 1) : E(i, 3); };
+    auto end_event = [&](int i) { return (merged && i < (persist ? loop_from : iters) - 1) ? E(i, 1) : E(i, 3); };
     auto start_event = [&](int i) { return (i > 0 && sampled[i - 1]) ? end_event(i - 1) : E(i, 0); };
     auto ring_params = [&](int i) {                      // the reducer of iteration i - 1, riding in launch i (i = iters: the closing launch)
         RingParams rp; memset(&rp, 0, sizeof(rp));
@@ -1153,40 +1162,14 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
             rp.red_partials = ((i - 1) & 1) ? c->partials2.as<double>() : c->partials.as<double>(); rp.red_nblocks = (ns[i - 1] + BVH_THREADS - 1) / BVH_THREADS;
             rp.totals_row = trows + (size_t)(i - 1) * NSUM; rp.ps_in = loop_slot(slots, i - 1, 0); rp.ps_out = loop_slot(slots, i, 0);
             rp.stats = c->stats.as<icp_iter_stats>() + (i - 1); rp.n_src = ns[i - 1];
+            if (i == iters) rp.final_out = (PoseState*)(c->stats.as<char>() + stats_pad);
         }
         return rp;
     };
     if (!merged && (rc = rearm_handover(c))) return rc;
     HIPCK(c, hipEventRecord(c->events[0], c->stream));
-    if (persist) {
-        // every level: the reducer on the second stream (forked off here, joined below), the matcher grid on the context's; each level has
-        // its own section of the partial ring, so that a level's matcher never writes where the level before is still being re-armed
-        HIPCK(c, hipEventRecord(c->ev_fork, c->stream));
-        HIPCK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-        size_t pring_off = 0;
-        for (const Seg& sg : segs) {
-            const int i = sg.i0, nb = (ns[i] + BVH_THREADS - 1) / BVH_THREADS;
-            LoopParams L; memset(&L, 0, sizeof(L));
-            L.iters = sg.i1 - sg.i0; L.first = i; L.seed_first = 0; L.slots = slots; L.totals = trows; L.pring = c->pring.as<unsigned long long>() + pring_off; L.nb = nb;
-            { const char* e = getenv("ICP_HIP_LOOP_PRESLEEP"); L.presleep_eighths = e ? atoi(e) : 3; }
-            L.dictated = 0; L.stats = c->stats.as<icp_iter_stats>(); L.n_src = ns[i]; L.abort_word = run_fault; L.record_last = 0; L.clocks = d_clocks;
-#if ICP_DEBUG_TIMES
-            if ((rc = ensure(c, c->dbg_steps, (size_t)(ns[i] > 65536 ? ns[i] : 65536) * 4))) return rc;
-            L.dbg = c->dbg_steps.as<int>(); L.dbg_waves = nb * (BVH_THREADS / WAVE); { const char* e = getenv("ICP_HIP_DBG_ITER"); L.dbg_iter = e ? atoi(e) : -1; }
-#endif
-            pring_off += (size_t)PRING_DEPTH * NSUM_USED * nb;
-            QuerySet q{clouds[i], sels[i], ns[i], 0, p.color_icp != 0, false, orders[i]};
-            MergeLaunch ml; ml.loop = &L; ml.slot = nullptr; ml.partials = nullptr; memset(&ml.rp, 0, sizeof(ml.rp));
-            int fused = 0;
-            if ((rc = launch_match(c, q, &fused, &ml))) return rc;      // (first: nothing on the host may block between the two launches of a level)
-            if (!fused) { c->err = "k_icp_loop: the matcher did not take the fused path"; return ICP_ERR_HIP; }
-            hipLaunchKernelGGL(k_icp_loop_reducer, dim3(LOOP_RED + 1), dim3(RING_THREADS), 0, c->stream2, L);      // 2 x 34 fold blocks + the solver
-            HIPCK(c, hipGetLastError());
-        }
-        HIPCK(c, hipEventRecord(c->ev_join, c->stream2));
-        HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    }
-    for (int i = 0; i < iters && !persist; i++) {
+    const int m_end = persist ? loop_from : iters;       // iterations [0, m_end) run one launch each
+    for (int i = 0; i < m_end; i++) {
         icp_iter_stats* d_st = c->stats.as<icp_iter_stats>() + i;
         const bool ev = sampled[i] != 0;
         if (ev && !(i > 0 && sampled[i - 1])) HIPCK(c, hipEventRecord(E(i, 0), c->stream));
@@ -1214,19 +1197,49 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
             hipLaunchKernelGGL(k_rmse_finish, dim3(1), dim3(64), 0, c->stream, c->rmse_partials.as<double>(), 256, &d_st->rmse);
         }
         if (fontana && (rc = enqueue_fontana(c, &d_st->benchmark_error))) return rc;
-        if (merged && i == iters - 1) {                  // the closing launch: reducer of the last iteration, nothing behind it
-            hipLaunchKernelGGL(k_ring_reduce_solve, dim3(NSUM_USED), dim3(RING_THREADS), 0, c->stream, ring_params(iters));
+        if (merged && i == m_end - 1) {                  // the closing launch: reducer of the last of these iterations, nothing behind it to ride in
+            hipLaunchKernelGGL(k_ring_reduce_solve, dim3(NSUM_USED), dim3(RING_THREADS), 0, c->stream, ring_params(m_end));
             HIPCK(c, hipGetLastError());
         }
-        if (ev && !(merged && i < iters - 1)) HIPCK(c, hipEventRecord(E(i, 3), c->stream));
+        if (ev && !(merged && i < m_end - 1)) HIPCK(c, hipEventRecord(E(i, 3), c->stream));
+    }
+    if (persist) {
+        // every level: the reducer on the second stream (forked off here, joined below), the matcher grid on the context's; each level has
+        // its own section of the partial ring, so that a level's matcher never writes where the level before is still being re-armed
+        HIPCK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        size_t pring_off = 0;
+        for (const Seg& sg : segs) {
+            const int i = sg.i0, nb = (ns[i] + BVH_THREADS - 1) / BVH_THREADS;
+            LoopParams L; memset(&L, 0, sizeof(L));
+            L.iters = sg.i1 - sg.i0; L.first = i; L.seed_first = (i > 0 && i == loop_from && factors[i] == factors[i - 1] && ns[i - 1] == ns[i] && clouds[i] == clouds[i - 1]) ? 1 : 0; L.slots = slots; L.totals = trows; L.pring = c->pring.as<unsigned long long>() + pring_off; L.nb = nb;
+            { const char* e = getenv("ICP_HIP_LOOP_PRESLEEP"); L.presleep_eighths = e ? atoi(e) : 5; }
+            { const char* e = getenv("ICP_HIP_LOOP_WAVESLEEP"); L.wave_presleep_eighths = e ? atoi(e) : 0; }
+            L.dictated = 0; L.stats = c->stats.as<icp_iter_stats>(); L.n_src = ns[i]; L.abort_word = run_fault; L.record_last = 0; L.clocks = d_clocks;
+            L.final_out = (PoseState*)(c->stats.as<char>() + stats_pad); L.final_g = iters;
+#if ICP_DEBUG_TIMES
+            if ((rc = ensure(c, c->dbg_steps, (size_t)(ns[i] > 65536 ? ns[i] : 65536) * 4))) return rc;
+            L.dbg = c->dbg_steps.as<int>(); L.dbg_waves = nb * (BVH_THREADS / WAVE); { const char* e = getenv("ICP_HIP_DBG_ITER"); L.dbg_iter = e ? atoi(e) : -1; }
+#endif
+            pring_off += (size_t)PRING_DEPTH * NSUM_USED * nb;
+            QuerySet q{clouds[i], sels[i], ns[i], 0, p.color_icp != 0, false, orders[i]};
+            MergeLaunch ml; ml.loop = &L; ml.slot = nullptr; ml.partials = nullptr; memset(&ml.rp, 0, sizeof(ml.rp));
+            int fused = 0;
+            if ((rc = launch_match(c, q, &fused, &ml))) return rc;      // (first: nothing on the host may block between the two launches of a level)
+            if (!fused) { c->err = "k_icp_loop: the matcher did not take the fused path"; return ICP_ERR_HIP; }
+            hipLaunchKernelGGL(k_icp_loop_reducer, dim3(LOOP_RED + 1), dim3(RING_THREADS), 0, c->stream2, L);      // 2 x 34 fold blocks + the solver
+            HIPCK(c, hipGetLastError());
+        }
+        HIPCK(c, hipEventRecord(c->ev_join, c->stream2));
+        HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     }
     HIPCK(c, hipEventRecord(c->events[1], c->stream));
     std::vector<icp_iter_stats> hs((size_t)iters);
-    const PoseState* d_final = merged ? loop_slot(slots, iters, 0) : c->ps.as<PoseState>();
-    if (persist) HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_pose + 192, d_clocks, (size_t)(iters + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_stats, c->stats.p, (size_t)iters * sizeof(icp_iter_stats), hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_pose, d_final, sizeof(PoseState), hipMemcpyDeviceToHost, c->stream));
-    if (merged) HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_pose + 128, run_fault, 4, hipMemcpyDeviceToHost, c->stream));
+    if (merged) HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_stats, c->stats.p, stats_pad + 192 + (persist ? (size_t)(iters + 1) * 8 : 0), hipMemcpyDeviceToHost, c->stream));      // records | final pose state | fault | clocks
+    else {
+        HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_stats, c->stats.p, (size_t)iters * sizeof(icp_iter_stats), hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipMemcpyAsync((char*)c->pinned + pin_pose, c->ps.p, sizeof(PoseState), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCK(c, hipStreamSynchronize(c->stream));
     if (merged) {
         if (persist) c->loop_runs++; else c->merged_runs++;
@@ -1262,29 +1275,32 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     icp_timing& t = c->timing; memset(&t, 0, sizeof(t)); t.iterations = iters;
     int n_sampled = 0;
     c->it_match_ms.assign((size_t)iters, -1.f); c->it_post_ms.assign((size_t)iters, -1.f); c->it_solve_ms.assign((size_t)iters, -1.f);
-    if (persist) {                                        // the device's own clock at every published pose: 100 MHz ticks
+    double ev_match = 0, ev_post = 0, ev_solve = 0; int n_ev = 0;
+    for (int i = 0; i < m_end; i++) {
+        if (!sampled[i]) continue;
+        n_ev++;
+        float a = 0, b = 0, d = 0;
+        HIPCK(c, hipEventElapsedTime(&a, start_event(i), E(i, 1)));
+        if (post_event[i]) HIPCK(c, hipEventElapsedTime(&b, E(i, 1), E(i, 2)));
+        if (!(merged && i < m_end - 1)) HIPCK(c, hipEventElapsedTime(&d, post_event[i] ? E(i, 2) : E(i, 1), E(i, 3)));
+        ev_match += a; ev_post += b; ev_solve += d;
+        c->it_match_ms[(size_t)i] = a; c->it_post_ms[(size_t)i] = b; c->it_solve_ms[(size_t)i] = d;
+        if (c->trace) fprintf(stderr, "[icp_hip] it %2d  n %d  match %.4f  post %.4f  solve %.4f ms\n", i, ns[i], a, b, d);
+    }
+    if (n_ev > 0) {                                       // sampled: scale to all the iterations that ran one launch each
+        const double f = (double)m_end / n_ev;
+        t.match_ms += ev_match * f; t.weight_reject_build_ms += ev_post * f; t.solve_ms += ev_solve * f;
+    }
+    n_sampled = n_ev;
+    if (persist) {                                        // k_icp_loop: the device's own clock at every published pose, 100 MHz ticks, every iteration
         const long long* clk = (const long long*)((char*)c->pinned + pin_pose + 192);
-        for (int i = 0; i < iters; i++) {
+        for (int i = loop_from; i < iters; i++) {
             const float a = (float)((double)(clk[i + 1] - clk[i]) * 1e-5);
             t.match_ms += a; c->it_match_ms[(size_t)i] = a; c->it_post_ms[(size_t)i] = 0.f; c->it_solve_ms[(size_t)i] = 0.f;
             if (c->trace) fprintf(stderr, "[icp_hip] it %2d  n %d  iteration %.4f ms (k_icp_loop)\n", i, ns[i], a);
         }
-        n_sampled = iters;
-    }
-    for (int i = 0; i < iters && !persist; i++) {
-        if (!sampled[i]) continue;
-        n_sampled++;
-        float a = 0, b = 0, d = 0;
-        HIPCK(c, hipEventElapsedTime(&a, start_event(i), E(i, 1)));
-        if (post_event[i]) HIPCK(c, hipEventElapsedTime(&b, E(i, 1), E(i, 2)));
-        if (!(merged && i < iters - 1)) HIPCK(c, hipEventElapsedTime(&d, post_event[i] ? E(i, 2) : E(i, 1), E(i, 3)));
-        t.match_ms += a; t.weight_reject_build_ms += b; t.solve_ms += d;
-        c->it_match_ms[(size_t)i] = a; c->it_post_ms[(size_t)i] = b; c->it_solve_ms[(size_t)i] = d;
-        if (c->trace) fprintf(stderr, "[icp_hip] it %2d  n %d  match %.4f  post %.4f  solve %.4f ms\n", i, ns[i], a, b, d);
-    }
-    if (n_sampled > 0 && n_sampled < iters) {             // sampled: scale to the whole run
-        const double f = (double)iters / n_sampled;
-        t.match_ms *= f; t.weight_reject_build_ms *= f; t.solve_ms *= f;
+        n_sampled += iters - loop_from;
+        if (n_ev == 0 && m_end > 0) { const double f = (double)iters / (iters - loop_from); t.match_ms *= f; }      // nothing timed in front: the loop's iterations stand for all
     }
     t.sampled_iterations = n_sampled;
     float tot = 0; HIPCK(c, hipEventElapsedTime(&tot, c->events[0], c->events[1])); t.total_ms = tot;

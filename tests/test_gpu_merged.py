@@ -70,7 +70,8 @@ def test_merged_loop_fullsize_is_bit_identical_to_separate_launches(gpu_ctx_fact
         assert (runs, fallbacks) == ((0, 0) if form == "separate" else (3, 0))
         if form == "loop":                                      # its iteration times come from the device's own clock, every iteration
             a, _, _ = c.iteration_times()
-            assert len(a) == 50 and (a > 0).all() and a[0] > a[-1]
+            lf = int(os.environ.get("ICP_HIP_LOOP_FROM", "0"))       # (iterations in front of it run one launch each: event-sampled)
+            assert len(a) == 50 and (a[lf:] > 0).all() and a[lf] > a[-1]
         t = c.timing()
         assert t["iterations"] == 50 and t["match_ms"] > 0
         c.close()
