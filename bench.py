@@ -465,7 +465,9 @@ def main():
                                    "solve": acc["solve_ms"] / launches},
         "per_regime_ms": per_regime,
         "n_valid_first": recs[0]["n_valid"] if recs else None, "n_valid_last": recs[-1]["n_valid"] if recs else None,
-        "roofline": {"kernel": "k_knn_bvh_post<3> (exact BVH 1-NN + weight/reject/accumulate epilogue, one launch per iteration)" if fused else "k_knn_brute<3>",
+        "roofline": {"kernel": ("k_knn_bvh_post_ring<3, false> (one launch per iteration: exact BVH 1-NN + weight/reject/accumulate epilogue; its first 34 blocks fold the previous "
+                                "iteration's partials and solve -- the matcher blocks wait for that pose after issuing their loads)" if os.environ.get("ICP_HIP_MERGE", "1") != "0" else
+                                "k_knn_bvh_post<3, false> (exact BVH 1-NN + weight/reject/accumulate epilogue, one launch per iteration; k_reduce_solve separate)") if fused else "k_knn_brute<3>",
                      "bound": "hbm", "achieved": achieved if have_stage else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS if have_stage else None, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": alg_bytes, "match_only_bytes_per_launch": match_bytes,
@@ -473,8 +475,10 @@ def main():
                      "avg_launch_ms": knn_ms if have_stage else None,
                      "timed_launches": acc["sampled_iterations"], "launches": acc["iterations"],
                      "note": "algorithmic bytes = SURVEY.md 8d per-iteration figure for what ONE launch of the named kernel does (fused: match 32 B/query "
-                             "+ 12 B/target and weight/reject/accumulate 56 B/query); duration = HIP events on the context's stream around the matcher of "
-                             "every %s iteration of the timed region (offset rotating per step)" % ("" if args.stage_timing == 1 else "%d-th" % args.stage_timing)},
+                             "+ 12 B/target and weight/reject/accumulate 56 B/query); duration = HIP events on the context's stream around the launch of "
+                             "every %s iteration of the timed region (offset rotating per step); in the merged form that launch also holds the reduce + solve of "
+                             "the iteration before (no separate solve stage: stage_ms_per_iteration.solve is the closing launch of a run only)"
+                             % ("" if args.stage_timing == 1 else "%d-th" % args.stage_timing)},
         "pose_error_vs_gt": {"rot_rad": rot_err, "trans_m": trans_err},
         "pose_gather": gather.kind,
         "pairs_per_rank": [R] * world, "max_over_ranks_step_ms": elapsed / args.steps * 1e3,
