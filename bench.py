@@ -215,7 +215,18 @@ def batch_mode(args, world, rank, local_rank):
     import torch.distributed as dist
     from icp_amd import binding, synth, batch
     mine = batch.shard_pairs(args.pairs, rank, world)
-    scans = [synth.eth_like_pair(p % 44, n_tilt=args.n_tilt, n_beam=args.n_beam) for p in mine]
+    if args.shared_scans and world == 1:
+        # the ETH loop's shape (main.cpp:411-498): pair p aligns scan p + 1 to scan p, the perturbation is the INITIAL POSE (main.cpp:420-429);
+        # scan p + 1 is handed over as the SAME arrays to pair p (source) and pair p + 1 (target): icp_batch_run uploads it once per run of pairs
+        raw = [synth.laser_scan(synth.scan_pose(k % 45, 0xE7A0), 0xE7A0 + k % 45, args.n_tilt, args.n_beam, 0.01) for k in range(args.pairs + 1)]
+        scans = []; init = []
+        for p in mine:
+            Tp = synth.perturbation(0xE7A0 + 100003 * (p + 1))
+            scans.append(dict(src_pts=raw[p + 1][0], src_nrm=raw[p + 1][1], tgt_pts=raw[p][0], tgt_nrm=raw[p][1], gt=np.eye(4)))
+            init.append(Tp)
+    else:
+        scans = [synth.eth_like_pair(p % 44, n_tilt=args.n_tilt, n_beam=args.n_beam) for p in mine]
+        init = None
     n_ctx = max(1, args.contexts)
     opts = [make_optimizer(binding, local_rank, args) for _ in range(n_ctx)]
     for o in opts:
@@ -224,7 +235,7 @@ def batch_mode(args, world, rank, local_rank):
     gather = PoseGather(world, rank, local_rank, args.gather, "cuda", args.allow_gather_fallback)
 
     def step():
-        local, status, rc = binding.batch_run(ctxs, scans)
+        local, status, rc = binding.batch_run(ctxs, scans, init)
         if rc != 0:
             raise SystemExit("icp_batch_run failed: %s" % status.tolist())
         return gather.gather(local, args.pairs)
@@ -256,7 +267,7 @@ def batch_mode(args, world, rank, local_rank):
            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "configs[3]: %d consecutive synthetic ETH-like pairs, pair p -> rank p mod N, exact %s k-NN + point-to-plane, "
                                   "%d iterations per pair, host->device uploads and index builds inside the timed region, one pose gather per step"
-                                  % (args.pairs, args.knn, args.iterations), "pairs": args.pairs, "contexts_per_gpu": n_ctx},
+                                  % (args.pairs, args.knn, args.iterations), "pairs": args.pairs, "contexts_per_gpu": n_ctx, "shared_scans": bool(args.shared_scans and world == 1)},
            "pairs_per_s": args.pairs * args.steps / elapsed, "correspondences_per_s": value * n_src, "pose_gather": gather.kind,
            "pairs_per_rank": [len(batch.shard_pairs(args.pairs, r, world)) for r in range(world)], "max_over_ranks_step_ms": elapsed / args.steps * 1e3,
            "max_trans_err_vs_gt_m_rank0": max(errs) if errs else None}
@@ -303,6 +314,8 @@ def main():
     ap.add_argument("--contexts", type=int, default=4, help="batch mode: contexts (= HIP streams, host threads) per rank")
     ap.add_argument("--pairs", type=int, default=0, help="batch mode (configs[3]): align this many consecutive scan pairs per step, "
                     "sharded pair p -> rank p mod N, uploads and index builds INSIDE the timed region, one pose gather per step")
+    ap.add_argument("--shared-scans", action="store_true", help="batch mode on one rank: the batch is a scan SEQUENCE (pair p = scans p, p + 1 as the same arrays; the perturbation is "
+                    "the initial pose, as in the reference's ETH loop): icp_batch_run uploads a shared scan once per run of pairs")
     ap.add_argument("--gather", choices=["cabi", "torch"], default="cabi", help="pose gather: ncclAllGather from the C ABI (default) or torch.distributed")
     ap.add_argument("--allow-gather-fallback", action="store_true", help="if the C-ABI communicator cannot be created on every rank, gather with "
                     "torch.distributed.all_gather instead of stopping (the line then says so in `pose_gather`)")

@@ -62,6 +62,18 @@ __global__ void k_colors(const uint8_t* __restrict__ rgba, int n, int pad_to, ui
     } else if (i < pad_to) { cr[i] = 0.f; cg[i] = 0.f; cb[i] = 0.f; }
 }
 
+// A resident source cloud becomes the target of the next pair (consecutive scan pairs share a scan: icp_batch_run): plane by plane, with the
+// target's +inf padding.  src / dst: 6 planes (x y z nx ny nz), grid.y = plane.
+struct Planes6 { const float* s[6]; float* d[6]; };
+__global__ void k_copy_planes_pad(const Planes6 pl, int n, int pad_to) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    const float* __restrict__ s = nullptr; float* __restrict__ d = nullptr;
+#pragma unroll
+    for (int q = 0; q < 6; q++) if (q == k) { s = pl.s[q]; d = pl.d[q]; }
+    if (!s || !d) return;
+    if (i < n) d[i] = s[i];
+    else if (i < pad_to && k < 3) d[i] = INFINITY;
+}
 __global__ void k_fill_u64(unsigned long long* p, int n, unsigned long long v) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;

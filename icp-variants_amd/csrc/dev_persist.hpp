@@ -314,9 +314,7 @@ __device__ __forceinline__ void loop_matcher(const LoopK<DIM>& K) {
         QueryIn<DIM> in;
         if (!have) {
             fused_front_loads<DIM>(kp, pp, bv, k, seeded, inc, in);
-#ifndef ICP_LOOP_NOHAVE
             if (DIM == 3 && inc) { loop_park<DIM>(bvh_lbq, tid, in); q0_kept = in.q0; }      // (a walk of this wave overwrites the rows: then nobody reads them back)
-#endif
         } else { loop_unpark<DIM>(bvh_lbq, tid, in); in.q0 = q0_kept; }
         // A query of the two-leaf tier pays three dependent trips to memory behind the pose (second-tier bound -> two leaves), and with it
         // its wave and the wave it shares the block barrier with: the last ones of every converged iteration by 5 us (tools/dev_loop_times.py).
@@ -345,15 +343,11 @@ __device__ __forceinline__ void loop_matcher(const LoopK<DIM>& K) {
 #if ICP_DEBUG_TIMES
         { const int ns_ = __popcll(__ballot(searched)), nr_ = __popcll(__ballot(renewed)); if (L.dbg && g == L.dbg_iter && lane == 0) { L.dbg[8 * wave_slot + 5] = ns_ | (nr_ << 8) | ((have ? 1 : 0) << 16); } }
 #endif
-#ifdef ICP_LOOP_NOHAVE
-        have = false;
-#else
         // (a query of the two-leaf tier -- a handful sit between two targets and take it in EVERY iteration -- gives its new state back: parked
         //  again, the wave keeps everything; reloading it all from memory made those few waves the last of every converged iteration by 6 us)
         have = DIM == 3 && inc && !__any(searched);
         renew_mask = __ballot(renewed);
         if (have && renewed) { loop_park<DIM>(bvh_lbq, tid, in); q0_kept = in.q0; }
-#endif
         unsigned long long* prow = L.pring + (size_t)(it % PRING_DEPTH) * NSUM_USED * L.nb;
         const int nb = L.nb;
         fused_block_epilogue(kp, pp, o, bvh_lbq, tid, wave_slot, [=](int sum, double v) {

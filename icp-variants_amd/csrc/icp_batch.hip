@@ -31,30 +31,54 @@ int32_t icp_pairs_of_rank(int32_t n_pairs, int32_t rank, int32_t n_ranks) {
     return (n_pairs - rank + n_ranks - 1) / n_ranks;
 }
 
+int icp_internal_promote_source_to_target(icp_ctx* ctx);      // icp_hip.hip: the resident source becomes the target (no trip through the host)
+
+// A pair whose target IS the source of the pair before it (same arrays, same size, no colours): consecutive scan pairs (k, k + 1) share
+// scan k + 1 -- the reference loads it twice (main.cpp:411-498).
+static bool target_is_previous_source(const icp_pair& prev, const icp_pair& cur) {
+    return cur.tgt_xyz == prev.src_xyz && cur.tgt_normals == prev.src_normals && cur.n_tgt == prev.n_src && !cur.tgt_rgba && !prev.src_rgba && cur.tgt_xyz != nullptr;
+}
+
 int icp_batch_run(icp_ctx* const* ctxs, int32_t n_ctx, const icp_pair* pairs, int32_t n_pairs, float* poses_out, int32_t* status_out) {
     if (!ctxs || n_ctx <= 0 || n_pairs < 0 || (n_pairs > 0 && (!pairs || !poses_out))) return ICP_ERR_INVALID_ARG;
     for (int i = 0; i < n_ctx; i++) if (!ctxs[i]) return ICP_ERR_INVALID_ARG;
     std::vector<int32_t> st((size_t)n_pairs, ICP_OK);
+    const int nt = n_ctx < n_pairs ? n_ctx : n_pairs;
+    // A batch in which every pair's target is the source of the pair before it (a scan sequence) is dealt out in CONTIGUOUS runs, one per
+    // context: inside a run the shared scan is uploaded once -- as the source of pair k; it is then promoted to the target of pair k + 1 on
+    // the device.  Any other batch: every thread takes the next pair that has not been started.
+    bool chain = n_pairs > 1;
+    for (int32_t p = 1; p < n_pairs && chain; p++) chain = target_is_previous_source(pairs[p - 1], pairs[p]);
     std::atomic<int32_t> next(0);
-    auto worker = [&](icp_ctx* c) {
+    auto align = [&](icp_ctx* c, int32_t p, bool promote) {
+        const icp_pair& q = pairs[p];
+        float* pose = poses_out + (size_t)p * 16;
+        memcpy(pose, q.initial_pose, 64);
+        int rc = promote ? icp_internal_promote_source_to_target(c)
+                         : icp_set_target(c, q.tgt_xyz, q.tgt_normals, q.tgt_rgba, q.n_tgt);                // buildIndex, ICPOptimizer.h:532-535
+        if (!rc) rc = icp_set_source(c, q.src_xyz, q.src_normals, q.src_rgba, q.n_src);
+        if (!rc) { int32_t n = 0; rc = icp_run(c, pose, nullptr, 0, &n); }                           // estimatePose, main.cpp:457
+        st[(size_t)p] = rc;
+        return rc;
+    };
+    auto worker = [&](icp_ctx* c, int t) {
+        if (chain) {
+            const int32_t lo = (int32_t)((long long)n_pairs * t / nt), hi = (int32_t)((long long)n_pairs * (t + 1) / nt);
+            bool src_resident = false;                      // the context holds pairs[p - 1]'s source, untouched since its upload
+            for (int32_t p = lo; p < hi; p++) src_resident = align(c, p, src_resident) == ICP_OK;
+            return;
+        }
         for (;;) {
             const int32_t p = next.fetch_add(1);
             if (p >= n_pairs) return;
-            const icp_pair& q = pairs[p];
-            float* pose = poses_out + (size_t)p * 16;
-            memcpy(pose, q.initial_pose, 64);
-            int rc = icp_set_target(c, q.tgt_xyz, q.tgt_normals, q.tgt_rgba, q.n_tgt);                  // buildIndex, ICPOptimizer.h:532-535
-            if (!rc) rc = icp_set_source(c, q.src_xyz, q.src_normals, q.src_rgba, q.n_src);
-            if (!rc) { int32_t n = 0; rc = icp_run(c, pose, nullptr, 0, &n); }                           // estimatePose, main.cpp:457
-            st[(size_t)p] = rc;
+            align(c, p, false);
         }
     };
-    const int nt = n_ctx < n_pairs ? n_ctx : n_pairs;
-    if (nt <= 1) { if (n_pairs > 0) worker(ctxs[0]); }
+    if (nt <= 1) { if (n_pairs > 0) worker(ctxs[0], 0); }
     else {
         std::vector<std::thread> th;
         th.reserve((size_t)nt);
-        for (int i = 0; i < nt; i++) th.emplace_back(worker, ctxs[i]);
+        for (int i = 0; i < nt; i++) th.emplace_back(worker, ctxs[i], i);
         for (auto& t : th) t.join();
     }
     int first = ICP_OK;

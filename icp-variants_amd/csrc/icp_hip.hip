@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cmath>
 #include "icp_device.hpp"
+#include <hip/hip_ext.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
@@ -88,6 +89,7 @@ struct icp_ctx {
     hipStream_t stream2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // k_icp_loop_reducer runs BESIDE the matcher grid: its own stream, forked off / joined to the context's
     int loop_capacity[4] = {0, 0, 0, 0}; // resident blocks of k_icp_loop<3/6, false/true> on this device (0: not asked yet)
     int merged_runs = 0, merged_fallbacks = 0;   // runs that took the merged loop / that had to be repeated with the separate launches (icp_debug_counters)
+    bool ext_events = true;              // merged form: stage times from hipExtLaunchKernel's start / stop events (ICP_HIP_EXT_EVENTS=0: hipEventRecord brackets)
     bool keep_fused_records = false;     // icp_match_seeded: the fused matcher also writes its Match records and distances (the loop itself never reads them)
     icp_params prm;
     Cloud tgt, src, qry;                 // qry: scratch cloud of icp_query_matches
@@ -268,7 +270,7 @@ int write_pose(icp_ctx* c, const float pose[16]) {
 }
 
 // One launch of the merged loop: the pose slot its matcher blocks wait for, where they leave their partials, and the reducer that rides in front.
-struct MergeLaunch { RingParams rp; const PoseState* slot; double* partials; const LoopParams* loop = nullptr; };   // loop != nullptr: k_icp_loop (all iterations of a level in one launch)
+struct MergeLaunch { RingParams rp; const PoseState* slot; double* partials; const LoopParams* loop = nullptr; hipEvent_t ev_start = nullptr, ev_stop = nullptr; };   // ev_start / ev_stop: the launch's own start / stop times go into these events (hipExtLaunchKernel: taken from the dispatch itself, no bracket on the stream)   // loop != nullptr: k_icp_loop (all iterations of a level in one launch)
 
 struct QuerySet { const Cloud* cl; const int* sel; int n; int pretransformed; bool use_colors; bool seed_prev; const int* order; };   // cl/sel: also what the post stage reads
 
@@ -480,7 +482,11 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
         }
         else if (ml) {                                                             // merged loop: reducer blocks in front, pose through the ring
             kf.ps = ml->slot; pp.ps = ml->slot; pp.partials = ml->partials;
-            if (b.Lq <= 8) hipLaunchKernelGGL((k_knn_bvh_post_ring<DIM, false>), dim3(nb + ml->rp.n_red), dim3(BVH_THREADS), lds, c->stream, kf, bv, order, pp, ml->rp);
+            if (ml->ev_start) {
+                if (b.Lq <= 8) hipExtLaunchKernelGGL((k_knn_bvh_post_ring<DIM, false>), dim3(nb + ml->rp.n_red), dim3(BVH_THREADS), (uint32_t)lds, c->stream, ml->ev_start, ml->ev_stop, 0, kf, bv, order, pp, ml->rp);
+                else hipExtLaunchKernelGGL((k_knn_bvh_post_ring<DIM, true>), dim3(nb + ml->rp.n_red), dim3(BVH_THREADS), (uint32_t)lds, c->stream, ml->ev_start, ml->ev_stop, 0, kf, bv, order, pp, ml->rp);
+            }
+            else if (b.Lq <= 8) hipLaunchKernelGGL((k_knn_bvh_post_ring<DIM, false>), dim3(nb + ml->rp.n_red), dim3(BVH_THREADS), lds, c->stream, kf, bv, order, pp, ml->rp);
             else hipLaunchKernelGGL((k_knn_bvh_post_ring<DIM, true>), dim3(nb + ml->rp.n_red), dim3(BVH_THREADS), lds, c->stream, kf, bv, order, pp, ml->rp);
         }
         else if (b.Lq <= 8) hipLaunchKernelGGL((k_knn_bvh_post<DIM, false>), dim3(nb), dim3(BVH_THREADS), lds, c->stream, kf, bv, order, pp);
@@ -747,6 +753,7 @@ int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out) {
     { const char* e = getenv("ICP_HIP_TIER2"); if (e && e[0] == '0') c->tier2 = false; }
     { const char* e = getenv("ICP_HIP_MERGE"); if (e && e[0] == '0') c->merge_loop = false; }
     { const char* e = getenv("ICP_HIP_PERSIST"); if (e) c->persist_loop = e[0] == '1'; }
+    { const char* e = getenv("ICP_HIP_EXT_EVENTS"); if (e && e[0] == '0') c->ext_events = false; }
     { const char* e = getenv("ICP_HIP_LOOP_FROM"); if (e) c->loop_from = atoi(e); }
     { const char* e = getenv("ICP_HIP_PRESORT"); if (e && e[0] == '0') c->presort = false; }
     { const char* e = getenv("ICP_HIP_BLOCK_LEVELS"); if (e && e[0] == '0') c->block_levels = false; }
@@ -825,6 +832,40 @@ int icp_set_target(icp_ctx* c, const float* xyz, const float* normals, const uin
         if (c->prm.color_icp && rgba) return guard.done(build_bvh<6>(c, c->bvh6, target_coords6(c)));
         return guard.done(build_bvh<3>(c, b, target_coords3(c)));
     }
+    return guard.done();
+}
+
+// Not part of icp_hip.h (icp_batch_run's own): the resident SOURCE becomes the target -- what icp_set_target(the same arrays) would leave,
+// without the trip through the host: consecutive scan pairs (k, k + 1) share scan k + 1, the source of pair k and the target of pair
+// k + 1 (main.cpp:411-498 loads it twice).  Plane copies on the device (+inf padding as upload_cloud does), then the same finite filter
+// and index build.  Colours are not carried (ICP_ERR_INVALID_ARG when colour ICP is on).
+int icp_internal_promote_source_to_target(icp_ctx* c) {
+    if (!c) return ICP_ERR_INVALID_ARG;
+    if (c->src.n <= 0) { c->err = "promote: no source cloud"; return ICP_ERR_NO_SOURCE; }
+    if (c->prm.color_icp || c->prm.weighting == ICP_WEIGHT_COLORS) { c->err = "promote: colours are not carried"; return ICP_ERR_INVALID_ARG; }
+    int rc;
+    DrainOnError guard(c);
+    if ((rc = set_device(c))) return rc;
+    const Cloud& sc = c->src; Cloud& tg = c->tgt;
+    const int n = sc.n, npad = ((n + 63) / 64) * 64;
+    for (DevBuf* pl : {&tg.x, &tg.y, &tg.z}) if ((rc = ensure(c, *pl, (size_t)npad * 4))) return rc;
+    if (sc.has_normals) for (DevBuf* pl : {&tg.nx, &tg.ny, &tg.nz}) if ((rc = ensure(c, *pl, (size_t)n * 4))) return rc;
+    Planes6 pl;
+    pl.s[0] = sc.x.as<float>(); pl.s[1] = sc.y.as<float>(); pl.s[2] = sc.z.as<float>();
+    pl.d[0] = tg.x.as<float>(); pl.d[1] = tg.y.as<float>(); pl.d[2] = tg.z.as<float>();
+    pl.s[3] = sc.has_normals ? sc.nx.as<float>() : nullptr; pl.s[4] = sc.has_normals ? sc.ny.as<float>() : nullptr; pl.s[5] = sc.has_normals ? sc.nz.as<float>() : nullptr;
+    pl.d[3] = sc.has_normals ? tg.nx.as<float>() : nullptr; pl.d[4] = sc.has_normals ? tg.ny.as<float>() : nullptr; pl.d[5] = sc.has_normals ? tg.nz.as<float>() : nullptr;
+    hipLaunchKernelGGL(k_copy_planes_pad, dim3((npad + 255) / 256, 6), dim3(256), 0, c->stream, pl, n, npad);
+    HIPCK(c, hipGetLastError());
+    tg.n = n; tg.npad = npad; tg.has_normals = sc.has_normals; tg.has_colors = false;
+    Bvh& b = c->bvh;
+    c->bvh6.valid = false;
+    b.valid = false; b.n_valid = 0;
+    if ((rc = finite_list(c, c->tgt, false, c->tgt_flag, c->tgt_finite, &b.n_valid))) return rc;
+    b.d_finite = c->tgt_finite.as<int>(); b.n_ids = n;
+    c->bvh6.d_finite = b.d_finite; c->bvh6.n_valid = b.n_valid; c->bvh6.n_ids = n;
+    b.attrs = &c->tgt; c->bvh6.attrs = &c->tgt;
+    if (c->prm.knn_backend == ICP_KNN_LBVH && c->prm.matching == ICP_MATCH_KNN) return guard.done(build_bvh<3>(c, b, target_coords3(c)));
     return guard.done();
 }
 
@@ -1153,7 +1194,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     c->timing_phase++;
     auto E = [&](int i, int k) { return c->events[(size_t)2 + 4 * i + k]; };
     auto end_event = [&](int i) { return (merged && i < (persist ? loop_from : iters) - 1) ? E(i, 1) : E(i, 3); };
-    auto start_event = [&](int i) { return (i > 0 && sampled[i - 1]) ? end_event(i - 1) : E(i, 0); };
+    auto start_event = [&](int i) { return (i > 0 && sampled[i - 1] && !(merged && c->ext_events)) ? end_event(i - 1) : E(i, 0); };
     auto ring_params = [&](int i) {                      // the reducer of iteration i - 1, riding in launch i (i = iters: the closing launch)
         RingParams rp; memset(&rp, 0, sizeof(rp));
         rp.run_fault = run_fault;
@@ -1172,7 +1213,8 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     for (int i = 0; i < m_end; i++) {
         icp_iter_stats* d_st = c->stats.as<icp_iter_stats>() + i;
         const bool ev = sampled[i] != 0;
-        if (ev && !(i > 0 && sampled[i - 1])) HIPCK(c, hipEventRecord(E(i, 0), c->stream));
+        const bool ext_ev = ev && merged && ns[i] > 0 && c->ext_events;      // merged form: the launch's own start / stop times, no bracket on the stream
+        if (ev && !ext_ev && !(i > 0 && sampled[i - 1] && !c->ext_events)) HIPCK(c, hipEventRecord(E(i, 0), c->stream));
         if (ns[i] > 0) {
             // seed the search with the previous iteration's neighbours when it matched the same queries (same level)
             const bool seed = i > 0 && factors[i] == factors[i - 1] && ns[i - 1] > 0 && p.selection == 0;
@@ -1180,9 +1222,10 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
             int fused = 0;
             MergeLaunch ml;
             if (merged) { ml.rp = ring_params(i); ml.slot = loop_slot(slots, i, 0); ml.partials = (i & 1) ? c->partials2.as<double>() : c->partials.as<double>(); }
+            if (ext_ev) { ml.ev_start = E(i, 0); ml.ev_stop = E(i, 1); }
             if ((rc = launch_match(c, q, c->fuse_post ? &fused : nullptr, merged ? &ml : nullptr))) return rc;
             if (merged && !fused) { c->err = "merged loop: the matcher did not take the fused path"; return ICP_ERR_HIP; }
-            if (ev) HIPCK(c, hipEventRecord(E(i, 1), c->stream));
+            if (ev && !ext_ev) HIPCK(c, hipEventRecord(E(i, 1), c->stream));
             // fused epilogue: there is no separate post stage to bracket
             if (!merged) {
                 if ((rc = launch_post_and_solve(c, *clouds[i], sels[i], ns[i], d_st, nullptr, 1, (ev && !fused) ? E(i, 2) : nullptr, fused))) return rc;

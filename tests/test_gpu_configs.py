@@ -108,6 +108,38 @@ def test_config3_batch_on_one_gpu(gpu_ctx_factory, orc, small_batch, knn):
     comm.close()
 
 
+def test_config3_batch_of_a_scan_sequence_shares_the_scans(gpu_ctx_factory, orc):
+    """The ETH loop aligns scan k + 1 to scan k for consecutive k (main.cpp:411-498): scan k + 1 is the source of pair k and the target of
+    pair k + 1.  Handed over as the SAME arrays, icp_batch_run uploads such a scan once per run of pairs and promotes it from source to
+    target on the device.  Same poses, bit for bit, as the batch built from copies (every target uploaded), with 1 or 3 contexts; and
+    every pose within 1e-5 of the oracle started from the same perturbed pose (main.cpp:420-429: the perturbation is the initial pose)."""
+    from conftest import pose_error
+    from icp_amd import binding, synth
+    iters = 30
+    scans = [synth.laser_scan(synth.scan_pose(k, 0xE7A0), 0xE7A0 + k, 36, 110, 0.01) for k in range(8)]
+    init = [synth.perturbation(0xE7A0 + 100003 * (k + 1)) for k in range(7)]
+    chain = [dict(src_pts=scans[k + 1][0], src_nrm=scans[k + 1][1], tgt_pts=scans[k][0], tgt_nrm=scans[k][1]) for k in range(7)]
+    copies = [{key: np.array(v, copy=True) for key, v in d.items()} for d in chain]
+    assert chain[1]["tgt_pts"] is chain[0]["src_pts"] and copies[1]["tgt_pts"] is not copies[0]["src_pts"]
+    ctxs = []
+    for _ in range(3):
+        c = gpu_ctx_factory()
+        c.params.max_distance = 10.0; c.params.metric = 1; c.params.n_iterations = iters; c.params.knn_backend = 1
+        c.push_params(); ctxs.append(c)
+    shared3, st, rc = binding.batch_run(ctxs, chain, init)
+    assert rc == 0 and st.tolist() == [0] * 7
+    shared1, _, rc1 = binding.batch_run(ctxs[:1], chain, init)
+    plain3, _, rc2 = binding.batch_run(ctxs, copies, init)
+    assert rc1 == 0 and rc2 == 0
+    assert np.array_equal(shared3, shared1) and np.array_equal(shared3, plain3)
+    for k, d in enumerate(chain):
+        kd = orc.KdTree(d["tgt_pts"])
+        prm = orc.make_params(metric=1, n_iterations=iters, max_distance=10.0, solver_mode=1, knn_kdtree=1); prm.kdtree = kd.h
+        po, _ = orc.estimate_pose(prm, d["src_pts"], d["src_nrm"], None, d["tgt_pts"], d["tgt_nrm"], None, init[k].astype(f32))
+        ang, tr = pose_error(binding.pose_from_c(shared3[k]), po)
+        assert ang < 1e-5 and tr < 1e-5, (k, ang, tr)
+
+
 def test_batch_run_reports_per_pair_errors(gpu_ctx_factory, small_batch):
     from icp_amd import binding
     c = gpu_ctx_factory()
