@@ -1,29 +1,32 @@
-// dev_persist.hpp -- the whole ICP loop of one resolution level as ONE launch: k_icp_loop (point-to-plane through the fused BVH matcher).
+// dev_persist.hpp -- the whole ICP loop of one resolution level as ONE launch: k_icp_loop + k_icp_loop_reducer (point-to-plane through the
+// fused BVH matcher).  EXPERIMENTAL: on with ICP_HIP_PERSIST=1, measured slower than the merged per-launch loop so far.
 // Part of icp_device.hpp (included from there, inside namespace icpdev); see that file for the build contract.
 // ------------------------------------------------------------------------------------------------
-// Why.  With one launch per iteration a converged iteration (nobody walks the tree) costs 14 us of matcher + 6.7 us of k_reduce_solve:
-// two launch floors (2 x 2.4 us), a burst of 76-84 bytes per query that re-reads, unchanged, what the previous launch had in registers
-// (source point, normal, search state, the neighbour's record), 4.7 us of arithmetic and three dependent trips to memory.  Riding the
-// reducer in front of the next matcher launch (the merged loop, dev_solve.hpp) removes one floor but its hand-overs then queue behind
-// the matcher's load burst (3-5 us per hop on a streaming CU instead of 1: measured 20.3 us per iteration against 14.5 + 6.7).  What
-// fits the measurements is to take the burst away: the waves stay resident from one iteration to the next and keep their queries'
-// data in registers; nothing but the hand-over granules moves while the run has converged.
+// Why.  With one launch per iteration a converged iteration (nobody walks the tree) pays a launch floor or two, a burst of 76-84 bytes per
+// query that re-reads, unchanged, what the previous launch had in registers (source point, normal, search state, the neighbour's
+// record), 4.7 us of arithmetic and three dependent trips to memory.  Riding the reducer in front of the next matcher launch (the merged
+// loop, dev_solve.hpp) removes one floor, but its hand-overs then queue behind the matcher's load burst (3-5 us per hop on a streaming CU
+// instead of 1).  Here the burst goes away: the matcher waves stay resident from one iteration to the next and keep their queries' data
+// (parked in LDS during the epilogue); nothing but hand-over granules moves while the run has converged.
 //
-// Structure.  Grid = n_red reducer blocks + nb matcher blocks, all resident at once (the host checks the grid against the occupancy of
-// the kernel and uses the per-launch loop otherwise).  Per iteration g:
-//   matcher block : [loads, unless its waves still hold them] -> waits for pose slot g -> transform / verify / search / weigh / reject ->
-//                   block partial (34 doubles) as self-validating 8-byte granules into ring slot g % PRING_DEPTH
-//   reducer blocks (a, h), a < 34, h < 2 : fold half h of row a of that ring slot as the granules arrive (the fold's loads ARE the polls; k_reduce_solve's
-//                   summation order, bit for bit), publishes total a into row g of the totals ring, puts the "empty" pattern back into
-//                   the granules it consumed
-//   reducer block 0 : polls the 34 totals, solves (lane-parallel LDL^T), publishes pose slot g + 1 and the record of iteration g
+// Structure.  TWO kernels side by side, on two streams: k_icp_loop -- nb matcher blocks of two waves, all resident at once (the host checks
+// nb + LOOP_RED + 1 against the kernel's occupancy and runs one launch per iteration otherwise) -- and k_icp_loop_reducer -- 2 x 34 fold
+// blocks and a one-wave solver, small enough (two waves, <= 112 VGPRs) for the holes the matcher grid leaves.  Per iteration g:
+//   matcher block   : [loads, unless its waves still hold what they parked] -> waits for ITS replica of pose slot g -> transform / verify /
+//                     search / weigh / reject -> block partial (34 doubles) as self-validating 8-byte granules into ring slot g % PRING_DEPTH
+//   fold block (a, h): folds half h of row a of that ring slot as the granules arrive (the fold's loads ARE the polls; k_reduce_solve's
+//                     summation order, bit for bit), publishes its part of total a into row g of the totals ring, then puts the "empty"
+//                     pattern back into the granules it consumed
+//   solver          : polls the 3 x 34 partial totals, solves (lane-parallel LDL^T), publishes pose slot g + 1 (every replica), the record
+//                     of iteration g and the device clock
 // Every hand-over is of the "granule" kind (one naturally aligned 8-byte sc1 store, sc1-load polls, no fences, no flags, no atomics; see
-// ring_reduce_solve in dev_solve.hpp for the conventions); the partial ring needs no counter either, because a reducer thread only
-// ever re-arms granules it has itself consumed, and waits for those stores before it publishes anything a later write to the same
-// granule could depend on (causality: re-arm(g) < total(g + 1) < pose(g + 2) < partial(g + 2)).
-// Every wait is bounded and watches the abort word: a waiter that gives up raises it, block 0 raises it together with a fault it
-// publishes (a pivot of the 6 x 6 system failed the rank test: the eigen fallback lives in k_reduce_solve only) -- the host then repeats
-// the run with one launch per iteration.
+// ring_reduce_solve in dev_solve.hpp for the conventions); the partial ring needs no counter either, because a fold thread only ever
+// re-arms granules it has itself consumed, and waits for those stores before it publishes anything a later write to the same granule
+// could depend on (causality: re-arm(g) < total(g + 1) < pose(g + 2) < partial(g + 2)).
+// Every wait is bounded and watches the abort word: a waiter that gives up raises it (the very first wait of a launch has a short bound:
+// it also tells whether the two kernels run side by side at all), the solver raises it together with a fault it publishes (a pivot of
+// the 6 x 6 system failed the rank test: the eigen fallback lives in k_reduce_solve only) -- the host then repeats the run with one
+// launch per iteration.
 #ifndef ICP_PRING_DEPTH
 #define ICP_PRING_DEPTH 2
 #endif

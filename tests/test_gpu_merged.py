@@ -15,7 +15,7 @@ f32 = np.float32
 LBVH = 1
 
 
-FORMS = ("loop", "merged", "separate")
+FORMS = ("loop", "hybrid", "merged", "separate")      # hybrid: merged launches for the first 7 iterations, k_icp_loop from there (ICP_HIP_LOOP_FROM)
 
 
 def make_ctx(factory, form, **params):
@@ -23,7 +23,8 @@ def make_ctx(factory, form, **params):
         form = "merged"
     elif form is False:
         form = "separate"
-    env = {"ICP_HIP_MERGE": "0" if form == "separate" else "1", "ICP_HIP_PERSIST": "1" if form == "loop" else "0"}      # read once, at icp_ctx_create
+    env = {"ICP_HIP_MERGE": "0" if form == "separate" else "1", "ICP_HIP_PERSIST": "1" if form in ("loop", "hybrid") else "0",
+           "ICP_HIP_LOOP_FROM": "7" if form == "hybrid" else "0"}                                              # read once, at icp_ctx_create
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -68,9 +69,9 @@ def test_merged_loop_fullsize_is_bit_identical_to_separate_launches(gpu_ctx_fact
             out.append((pose, recs))
         runs, fallbacks = counters(c)
         assert (runs, fallbacks) == ((0, 0) if form == "separate" else (3, 0))
-        if form == "loop":                                      # its iteration times come from the device's own clock, every iteration
+        if form in ("loop", "hybrid"):                          # its iteration times come from the device's own clock, every iteration
             a, _, _ = c.iteration_times()
-            lf = int(os.environ.get("ICP_HIP_LOOP_FROM", "0"))       # (iterations in front of it run one launch each: event-sampled)
+            lf = 7 if form == "hybrid" else 0                   # (iterations in front of it run one launch each: event-sampled)
             assert len(a) == 50 and (a[lf:] > 0).all() and a[lf] > a[-1]
         t = c.timing()
         assert t["iterations"] == 50 and t["match_ms"] > 0
@@ -101,12 +102,12 @@ def test_merged_loop_small_cases(gpu_ctx_factory, bunny, case):
         pose, recs, rc = c.run(np.eye(4), check=False)
         res.append((rc, pose, recs, counters(c)))
         c.close()
-    for r in res[:2]:
-        assert r[0] == res[2][0]
-        assert np.array_equal(r[1], res[2][1])
-        assert_same_run(r[2], res[2][2])
+    for r in res[:-1]:
+        assert r[0] == res[-1][0]
+        assert np.array_equal(r[1], res[-1][1])
+        assert_same_run(r[2], res[-1][2])
         assert r[3] == (1, 0)
-    assert res[2][3] == (0, 0)
+    assert res[-1][3] == (0, 0)
 
 
 def test_rank_deficient_system_leaves_the_merged_loop(gpu_ctx_factory, bunny):
@@ -116,7 +117,7 @@ def test_rank_deficient_system_leaves_the_merged_loop(gpu_ctx_factory, bunny):
     sp = (tp[:40] + f32(1.0)).copy(); sn = tn[:40].copy()          # 39 sources a metre away from everything ...
     sp[7] = tp[7] + f32(1e-4)                                      # ... and one on the surface
     res = []
-    for merge in ("loop", "separate", "merged", "separate"):
+    for merge in ("loop", "separate", "merged", "separate"):      # (results 0 and 2 against 1)
         c = make_ctx(gpu_ctx_factory, merge, max_distance=0.0003, n_iterations=6, rejection=0)
         c.set_target(tp, tn); c.set_source(sp, sn)
         pose, recs, rc = c.run(np.eye(4), check=False)
