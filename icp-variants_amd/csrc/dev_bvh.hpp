@@ -37,9 +37,15 @@
 #endif
 constexpr int BVH_LEAF = 8;
 #ifndef ICP_BVH_THREADS
-#define ICP_BVH_THREADS 128
+#define ICP_BVH_THREADS 256
 #endif
-constexpr int BVH_THREADS = ICP_BVH_THREADS;    // queries per block of the BVH matchers
+constexpr int BVH_THREADS = ICP_BVH_THREADS;    // threads per block of the BVH matchers
+#ifndef ICP_QUERIES_PER_WAVE
+#define ICP_QUERIES_PER_WAVE 64  // fused matcher: queries per wave; below 64 the remaining lanes carry no query of their own and only help (shared walk)
+#endif
+constexpr int BVH_QPW = ICP_QUERIES_PER_WAVE;
+constexpr int BVH_QPB = BVH_THREADS / 64 * BVH_QPW;     // queries per block of the fused matcher
+__host__ __device__ inline int fused_nblocks(int n) { return (n + BVH_QPB - 1) / BVH_QPB; }
 
 template <int DIM> struct BvhNodeT { float lo[DIM][2]; float hi[DIM][2]; float pad[DIM == 3 ? 4 : 8]; };   // 64 B / 128 B
 template <int DIM> struct BvhLeafT { float c[DIM][BVH_LEAF]; int idx[BVH_LEAF]; float pad[DIM == 3 ? 0 : 8]; };   // 128 B / 256 B
@@ -72,6 +78,7 @@ template <int DIM> struct BvhViewT {
     int n_valid;                  // finite target points in the tree
     int Lp;                       // leaves rounded up to a power of two
     CoordPtrs<DIM> tgt;           // target planes by original index (seeding)
+    const int* pos_of;            // [M] position (8 * leaf + slot) by original index (the inverse of recs[].idx; -1: not in the tree)
 };
 
 __device__ __forceinline__ unsigned long long spread21(unsigned int v) {   // 21 bits -> every third bit
@@ -351,7 +358,7 @@ __global__ __launch_bounds__(BLV_THREADS) void k_bvh_block_levels(const CoordPtr
 
 template <int DIM>
 __global__ void k_bvh_gather(const CoordPtrs<DIM> cp, const float* __restrict__ nx, const float* __restrict__ ny, const float* __restrict__ nz, const uint32_t* __restrict__ rgba,
-                             const int* __restrict__ sorted_idx, int n_valid, int n_slots, BvhLeafT<DIM>* __restrict__ leaves, TgtRec* __restrict__ recs) {
+                             const int* __restrict__ sorted_idx, int n_valid, int n_slots, BvhLeafT<DIM>* __restrict__ leaves, TgtRec* __restrict__ recs, int* __restrict__ pos_of) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
     BvhLeafT<DIM>* lf = leaves + (i / BVH_LEAF); const int t = i % BVH_LEAF;
@@ -364,6 +371,7 @@ __global__ void k_bvh_gather(const CoordPtrs<DIM> cp, const float* __restrict__ 
         r.x = cp.c[0][j]; r.y = cp.c[1][j]; r.z = cp.c[2][j]; r.idx = j;
         if (nx) { r.nx = nx[j]; r.ny = ny[j]; r.nz = nz[j]; }
         if (rgba) r.rgba = rgba[j];
+        pos_of[j] = i;
     } else {
 #pragma unroll
         for (int k = 0; k < DIM; k++) lf->c[k][t] = (k < 3) ? INFINITY : 0.f;
@@ -763,28 +771,76 @@ __device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, cons
 // Rows of the wave's LDS slots: 0 key, 1 key2 (runner-up entry), 2 (rest, position of the winner), 3-5 and 7-9 the lanes' own results,
 // query and normal parked meanwhile (so that a helper needs no registers of its own for them), 6 the donors' lane numbers (first half)
 // and the smallest skipped box bound per owner (second half).
-template <int DIM, int NT, class MaskT>
+// ---- the same hand-over between the WAVES of a block (XW) ------------------------------------------------------------------------
+// A launch lasts as long as its slowest wave, and all waves of the grid are resident from the start: a wave that ends early frees a
+// slot nobody fills (iteration 2 of configs[1]: mean wave end 48 us, launch 80 us).  With XW a block is made of waves from far-apart
+// places of the query order (fused_matcher_body, ICP_WAVE_STRIDE), and a wave that has nothing left to do -- its own walks are over, or
+// it had none -- adopts parked subtrees of the block's other waves through a small board in LDS:
+//   board  : XW_SLOTS items (owner's thread | level, node, the donor's running best / index / position), state word per slot
+//            0 free -> 2 (a donor lane claimed it by compare-and-swap, writes the item) -> 1 full -> 3 (a lane of an idle wave claimed it,
+//            reads the item) -> 0.  An idle wave takes slot i with lane i; from there on the wave's own hand-over spreads the work
+//            over its other lanes.
+//   out[w] : parts of wave w's queries that are on the board or held by lanes of OTHER waves; a wave's queries are complete when all its
+//            lanes are idle and out[w] = 0 (every fold into an owner's record comes before the decrement, LDS executes a wave's
+//            operations in order, the owner reads its record after it has seen the zero).
+//   nreg, ndone : waves that walk / whose queries are complete; a wave leaves when its own are complete and ndone >= nreg.  A wave
+//            that starts late (nreg counts it only then) may find the others gone: it then simply takes its own items back.
+//   idlew  : waves polling the board -- donors put items there only while somebody waits for them.
+// The fold is the one of the wave-level hand-over (atomic minima in the owner's record), with one difference: the plain write of the
+// winner's POSITION next to the 64-bit (distance, index) key is no longer ordered by lockstep, so an owner whose queries had help from
+// another wave checks the record at that position against the key's index and, on a mismatch, takes the position from the inverse
+// map (BvhViewT::pos_of).  Results are the exact neighbours as before; the bounds kept for the verify tests may differ from run to run
+// (never larger than what is true), i.e. WHICH queries search in a later iteration may differ, not what they find.
+#ifndef ICP_XW
+#define ICP_XW 1                 // 1: blocks of more than one wave share walks between their waves (DIM 3)
+#endif
+#ifndef ICP_XW_SLEEP
+#define ICP_XW_SLEEP 4
+#endif
+constexpr int XW_SLOTS = 64, XW_CTRL = 32;
+constexpr int XW_INTS = XW_CTRL + XW_SLOTS * 6;          // control words, slot states, items (2 x uint2 + int per slot)
+constexpr int XW_SPIN_LIMIT = 1 << 22;                   // polls of an idle wave (~0.3 us each) before it gives up and raises the fault word
+template <int DIM, int NT> constexpr bool xw_enabled() { return ICP_XW && DIM == 3 && NT > WAVE && NT / WAVE <= 8; }
+template <int DIM, int NT> constexpr size_t xw_lds_bytes() { return xw_enabled<DIM, NT>() ? (size_t)XW_INTS * 4 : 0; }
+// (block start, before the first __syncthreads of the kernel: thread t clears word t of the control block and the slot states)
+template <int NT> __device__ __forceinline__ void xw_init(uint2* lbq, int tid) { if (tid < XW_CTRL + XW_SLOTS) ((int*)(lbq + ICP_SHARE_ROWS * NT))[tid] = 0; }
+// is any wave of this block searching right now?  (a wave without walkers of its own asks once)
+template <int NT> __device__ __forceinline__ bool xw_block_is_searching(uint2* lbq) {
+    const int* xc = (const int*)(lbq + ICP_SHARE_ROWS * NT);
+    const int nreg = __builtin_amdgcn_readfirstlane(__hip_atomic_load(xc + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)), ndone = __builtin_amdgcn_readfirstlane(__hip_atomic_load(xc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    return nreg > ndone;
+}
+
+// MODE 0: the wave on its own; 1: XW, the wave's own walks (it leaves when its queries are complete, and takes items off the board while it
+// waits for parts of them that other waves hold); 2: XW, help only (xw_help: no queries of its own, rows 3.. of the wave untouched).
+template <int DIM, int NT, class MaskT, int MODE = 0>
 __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* p, float* keep3, bool need_walk, float& best, int& bi, int& bpos, float& lb_others, float& lb3, int& l2o,
-                                                uint2* __restrict__ lbq, int tid) {
-    const int lane = tid & 63, Lq = bv.Lq;
-    uint2* R = lbq + (tid & ~63);
+                                                uint2* __restrict__ lbq, int tid, int* fault = nullptr) {
+    constexpr bool XW = MODE != 0, HELP = MODE == 2;
+    static_assert(!XW || xw_enabled<DIM, NT>(), "cross-wave sharing: DIM 3, 2..8 waves per block");
+    const int lane = tid & 63, Lq = bv.Lq, wbase = tid & ~63, myw = tid >> 6;
+    uint2* R = lbq + wbase;                                               // this wave's columns of the rows
     constexpr unsigned int FMAXB = 0x7F7FFFFFu, NONE = 0x7F800000u;
-    unsigned long long* keys = (unsigned long long*)R;                    // keys[l]
-    R[3 * NT + lane] = make_uint2(__float_as_uint(best), (unsigned int)bi);
-    R[4 * NT + lane] = make_uint2((unsigned int)bpos, __float_as_uint(lb_others));
-    R[5 * NT + lane] = make_uint2(__float_as_uint(lb3), __float_as_uint(p[0]));
-    R[7 * NT + lane] = make_uint2(__float_as_uint(p[1]), __float_as_uint(p[2]));
-    R[8 * NT + lane] = make_uint2(__float_as_uint(keep3[0]), __float_as_uint(keep3[1]));
-    R[9 * NT + lane] = make_uint2(__float_as_uint(keep3[2]), (unsigned int)l2o);
-    keys[lane] = ~0ull;
-    keys[NT + lane] = ~0ull;                                               // row 1: the runner-up entry (distance, leaf)
-    R[2 * NT + lane] = make_uint2(FMAXB, 0xFFFFFFFFu);                     // row 2: (bound on the rest, position of the winner)
-    ((unsigned int*)(R + 6 * NT))[WAVE + lane] = FMAXB;                    // row 6, second half: smallest skipped box bound
+    unsigned long long* keys = (unsigned long long*)lbq;                  // keys[t]: row 0 of thread t (block-wide: an owner may sit in another wave)
+    int* xc = (int*)(lbq + ICP_SHARE_ROWS * NT);                          // XW: nreg, ndone, idlew, -, out[8], helped[8], ...
+    int* xstate = xc + XW_CTRL; uint2* xa = (uint2*)(xstate + XW_SLOTS); uint2* xb = xa + XW_SLOTS; int* xp = (int*)(xb + XW_SLOTS);
+    if (!HELP) {
+        R[3 * NT + lane] = make_uint2(__float_as_uint(best), (unsigned int)bi);
+        R[4 * NT + lane] = make_uint2((unsigned int)bpos, __float_as_uint(lb_others));
+        R[5 * NT + lane] = make_uint2(__float_as_uint(lb3), __float_as_uint(p[0]));
+        R[7 * NT + lane] = make_uint2(__float_as_uint(p[1]), __float_as_uint(p[2]));
+        R[8 * NT + lane] = make_uint2(__float_as_uint(keep3[0]), __float_as_uint(keep3[1]));
+        R[9 * NT + lane] = make_uint2(__float_as_uint(keep3[2]), (unsigned int)l2o);
+        keys[tid] = ~0ull;
+        keys[NT + tid] = ~0ull;                                            // row 1: the runner-up entry (distance, leaf)
+        R[2 * NT + lane] = make_uint2(FMAXB, 0xFFFFFFFFu);                 // row 2: (bound on the rest, position of the winner)
+        ((unsigned int*)(R + 6 * NT))[WAVE + lane] = FMAXB;                // row 6, second half: smallest skipped box bound
+    }
     QueryPt<DIM> qp;
     make_query<DIM>(bv, p, qp);
     float wb = best; int wi = bi, wp = bpos;
     unsigned int touched = 0u;
-    if (need_walk) {
+    if (!HELP && need_walk) {
         if (ICP_SEED_DESCENT && wp < 0) {                                 // first iteration: a greedy descent yields a real candidate (see knn_walk)
             int idx = 0;
             for (int L = 0; L < Lq; L++) {
@@ -804,11 +860,12 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
     // seed's bound -- handed on below like any other parked subtree.
     const unsigned long long wm = __ballot(need_walk);
     const int W = __popcll(wm);
-    const bool spread = ICP_SHARE_SPREAD && Lq > 0 && W * (Lq + 1) <= WAVE && wm == __ballot(need_walk && wp >= 0);
+    if (MODE == 1 && lane == 0) __hip_atomic_fetch_add(xc + 0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // nreg: this wave has queries that search
+    const bool spread = !HELP && ICP_SHARE_SPREAD && Lq > 0 && W > 0 && W * (Lq + 1) <= WAVE && wm == __ballot(need_walk && wp >= 0);
     if (ICP_PREFETCH_PATH && !spread && need_walk && wp >= 0) touched = quad_prefetch_path<DIM>(bv, wp >> 3);
     float b2 = FLT_MAX, b3 = FLT_MAX; int l2 = -1;
     unsigned int mlb = FMAXB;
-    int owner = need_walk ? lane : -1;                                    // whose query this lane is searching for; -1: idle
+    int owner = need_walk ? tid : -1;                                     // whose query this lane is searching for (thread of the block); -1: idle
     QuadStateT<MaskT> st; st.L = 0; st.idx = 0; st.pending = 0; st.alive = need_walk;
     float thr = fminf(wb * ICP_PRUNE_SLACK, FLT_MAX);
     // one node step on the child bounds of node (st.L, st.idx): nearest surviving child next, the other survivors parked
@@ -840,7 +897,7 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
         if (take) {
 #pragma unroll
             for (int a = 0; a < DIM; a++) { qp.p2[a].x = q[a]; qp.p2[a].y = q[a]; }
-            wb = sb; wi = si; wp = sp; owner = src;
+            wb = sb; wi = si; wp = sp; owner = wbase + src;
             thr = fminf(wb * ICP_PRUNE_SLACK, FLT_MAX);
             const int leaf = sp >> 3, skip = (leaf >> (2 * (Lq - L - 1))) & 3;          // the child of my node that lies on the path: the next level's lane has it
             st.L = L; st.idx = leaf >> (2 * (Lq - L)); st.alive = true;
@@ -852,6 +909,8 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
         }
         if (need_walk) { st.L = Lq; st.idx = wp >> 3; }                   // the walker itself: straight to the seed's leaf
     }
+    bool polling = false;                                                 // XW, wave-uniform: this wave is counted in idlew
+    int polls = 0;
     for (;;) {
         if (!st.alive && owner >= 0) {
             // this lane's (part of the) search is over: fold it into the owner's record.  Winner: 64-bit minimum of (distance, index).
@@ -861,7 +920,7 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
             // straight to the rest (smaller bound than needed, for this one iteration).
             const unsigned long long mykey = ((unsigned long long)__float_as_uint(wb) << 32) | (unsigned int)wi;
             const unsigned long long old = __hip_atomic_fetch_min(keys + owner, mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            unsigned int* bp = (unsigned int*)(R + 2 * NT + owner);       // {rest, position}
+            unsigned int* bp = (unsigned int*)(lbq + 2 * NT + owner);     // {rest, position}
             unsigned int rest = __float_as_uint(b3);
             unsigned long long e = ((unsigned long long)__float_as_uint(b2) << 32) | (unsigned int)l2;
             if (old < mykey) {
@@ -876,11 +935,47 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
                 if (hi != ~0ull && (unsigned int)lo != (unsigned int)hi) rest = min(rest, (unsigned int)(hi >> 32));
             }
             __hip_atomic_fetch_min(bp, rest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_min((unsigned int*)(R + 6 * NT) + WAVE + owner, mlb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (keys[owner] == mykey) bp[1] = (unsigned int)wp;
+            __hip_atomic_fetch_min((unsigned int*)(lbq + 6 * NT + (owner & ~63)) + WAVE + (owner & 63), mlb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__hip_atomic_load(keys + owner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == mykey) bp[1] = (unsigned int)wp;      // (XW: see the check at the end)
+            if (XW && (owner >> 6) != myw) __hip_atomic_fetch_sub(xc + 4 + (owner >> 6), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             owner = -1;
         }
-        if (!__any(st.alive)) break;
+        if (!__any(st.alive)) {
+            if (!XW) break;
+            // MODE 1: are this wave's queries complete (no part of them on the board or in another wave's lanes)?  Then it leaves at once --
+            // what it can do for the others comes after its own pairs are weighed (xw_help)
+            const bool complete = MODE == 1 && __builtin_amdgcn_readfirstlane(__hip_atomic_load(xc + 4 + myw, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0;
+            // otherwise the idle wave takes what is on the board (lane i looks at slot i)
+            const int sv = complete ? 0 : __hip_atomic_load(xstate + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            bool mine = false;
+            if (sv == 1) { int expect = 1; mine = __hip_atomic_compare_exchange_strong(xstate + lane, &expect, 3, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            if (mine) {
+                const uint2 ia = xa[lane], ib = xb[lane]; const int ip = xp[lane];
+                __hip_atomic_store(xstate + lane, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                owner = (int)(ia.x & 0xFFFFu);
+                if ((owner >> 6) == myw) __hip_atomic_fetch_sub(xc + 4 + myw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // back home
+                const uint2 c = lbq[5 * NT + owner], d = lbq[7 * NT + owner];
+                qp.p2[0].x = __uint_as_float(c.y); qp.p2[0].y = qp.p2[0].x; qp.p2[1].x = __uint_as_float(d.x); qp.p2[1].y = qp.p2[1].x; qp.p2[2 % DIM].x = __uint_as_float(d.y); qp.p2[2 % DIM].y = qp.p2[2 % DIM].x;
+                wb = __uint_as_float(ib.x); wi = (int)ib.y; wp = ip;
+                b2 = FLT_MAX; b3 = FLT_MAX; l2 = -1; mlb = FMAXB;
+                thr = fminf(wb * ICP_PRUNE_SLACK, FLT_MAX);
+                st.L = (int)(ia.x >> 16); st.idx = (int)ia.y; st.pending = 0; st.alive = true;
+            }
+            if (__any(mine)) {
+                if (polling) { polling = false; if (lane == 0) __hip_atomic_fetch_sub(xc + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            } else {
+                if (MODE == 1) {
+                    if (complete) { if (lane == 0) __hip_atomic_fetch_add(xc + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }      // ndone
+                } else {
+                    const int ndone = __builtin_amdgcn_readfirstlane(__hip_atomic_load(xc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)), nreg = __builtin_amdgcn_readfirstlane(__hip_atomic_load(xc + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if (ndone >= nreg) break;                             // every wave that searched is complete
+                }
+                if (!polling) { polling = true; if (lane == 0) __hip_atomic_fetch_add(xc + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                if (++polls > XW_SPIN_LIMIT) { if (fault && lane == 0) atomicOr(fault, 1); break; }      // (cannot happen: every part is held by a running lane or lies on the board)
+                __builtin_amdgcn_s_sleep(ICP_XW_SLEEP);
+                continue;
+            }
+        }
         bool served = true;                                               // wave-uniform: no idle lane is left without work
 #pragma unroll 1
         for (int round = 0; round < ICP_SHARE_ROUNDS; round++) {
@@ -917,6 +1012,37 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
                     b2 = FLT_MAX; b3 = FLT_MAX; l2 = -1; mlb = FMAXB;
                     thr = fminf(wb * ICP_PRUNE_SLACK, FLT_MAX);
                     st.L = sL; st.idx = sI; st.pending = 0; st.alive = true;
+                    if (XW && (so >> 6) != myw) __hip_atomic_fetch_add(xc + 4 + (so >> 6), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // one more part of that wave's query in foreign hands
+                }
+            }
+        }
+        if (XW && served && __builtin_amdgcn_readfirstlane(__hip_atomic_load(xc + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) > 0) {
+            // another wave of the block waits for work and this wave's own lanes are all busy: lanes that still have parked subtrees put
+            // their shallowest one on the board
+            const bool can = st.alive && st.pending != 0;
+            const unsigned long long dm = __ballot(can);
+            if (dm) {
+                const int sv = __hip_atomic_load(xstate + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const unsigned long long fm = __ballot(sv == 0);
+                const int n = min(__popcll(dm), __popcll(fm));
+                int* tbl = (int*)(R + 6 * NT);
+                const int rf = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(fm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)fm, 0u));
+                if (sv == 0 && rf < n) tbl[rf] = lane;                    // the rf-th free slot
+                const int rd = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)dm, 0u));
+                if (can && rd < n) {
+                    const int slot = tbl[rd];
+                    int expect = 0;
+                    if (__hip_atomic_compare_exchange_strong(xstate + slot, &expect, 2, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        const int low = sizeof(MaskT) == 8 ? __ffsll((long long)st.pending) - 1 : __ffs((int)st.pending) - 1;
+                        const int lv = low >> 2;
+                        st.pending &= ~((MaskT)1 << low);
+                        xa[slot] = make_uint2((unsigned int)owner | ((unsigned int)(lv + 1) << 16), (unsigned int)(((st.idx >> (2 * (st.L - lv))) << 2) | (low & 3)));
+                        xb[slot] = make_uint2(__float_as_uint(wb), (unsigned int)wi);
+                        xp[slot] = wp;
+                        __hip_atomic_fetch_add(xc + 4 + (owner >> 6), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(xc + 12 + (owner >> 6), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // that wave's queries had outside help
+                        __hip_atomic_store(xstate + slot, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
         }
@@ -936,14 +1062,16 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
             quad_pop_bits(st);
         }
     }
+    if (XW && polling && lane == 0) __hip_atomic_fetch_sub(xc + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::"v"(touched));
+    if (HELP) return;
     {
         const uint2 c = R[5 * NT + lane], d = R[7 * NT + lane], e = R[8 * NT + lane], f = R[9 * NT + lane];
         p[0] = __uint_as_float(c.y); p[1] = __uint_as_float(d.x); p[2] = __uint_as_float(d.y);
         keep3[0] = __uint_as_float(e.x); keep3[1] = __uint_as_float(e.y); keep3[2] = __uint_as_float(f.x);
     }
     if (need_walk) {
-        const unsigned long long key = keys[lane], key2 = keys[NT + lane];
+        const unsigned long long key = keys[tid], key2 = keys[NT + tid];
         const uint2 b = R[2 * NT + lane];
         best = __uint_as_float((unsigned int)(key >> 32)); bi = (int)(unsigned int)key; bpos = (int)b.y;
         const float sk = __uint_as_float(((const unsigned int*)(R + 6 * NT))[WAVE + lane]);
@@ -953,12 +1081,26 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
         lb_others = sqrt_dn(fminf(__uint_as_float((unsigned int)(key2 >> 32)), rest));
         lb3 = sqrt_dn(rest);
         l2o = key2 == ~0ull ? -1 : (int)(unsigned int)key2;
+        if (XW && __builtin_amdgcn_readfirstlane(__hip_atomic_load(xc + 12 + myw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+            // lanes of other waves folded into this record: the position written beside the key may belong to a fold that lost
+            if (bpos < 0 || bv.recs[bpos].idx != bi) bpos = bv.pos_of[bi];
+        }
     } else {
         const uint2 a = R[3 * NT + lane], b = R[4 * NT + lane], c = R[5 * NT + lane];
         best = __uint_as_float(a.x); bi = (int)a.y; bpos = (int)b.x; lb_others = __uint_as_float(b.y); lb3 = __uint_as_float(c.x); l2o = (int)R[9 * NT + lane].y;
     }
 }
 
+
+// XW, a wave that has nothing of its own left to do (its pairs are weighed, only the block's sums remain): help the block's other waves
+// until every wave that searched is complete.  The wave's rows 3.. are not touched (the caller parks its pair there).
+template <int DIM, int NT, class MaskT>
+__device__ __forceinline__ void xw_help(const BvhViewT<DIM>& bv, uint2* __restrict__ lbq, int tid, int* fault) {
+    float p[DIM], k3[3] = {0.f, 0.f, 0.f}, best = FLT_MAX, lbo = 0.f, lb3 = 0.f; int bi = -1, bpos = -1, l2 = -1;
+#pragma unroll
+    for (int q = 0; q < DIM; q++) p[q] = 0.f;
+    knn_walk_shared<DIM, NT, MaskT, 2>(bv, p, k3, false, best, bi, bpos, lbo, lb3, l2, lbq, tid, fault);
+}
 
 __device__ __forceinline__ float wave_min_f32(float v) {
 #pragma unroll

@@ -33,6 +33,9 @@ struct P2pGen {                                           // values 0..21 = sum 
 // query, a stable 8-class rank in the epilogue): iterations 1-9 0.084 vs 0.079 ms -- the prediction is not worth the extra dependent
 // load in front of everything and the gathers.  What did pay was making k_reduce_solve itself cheaper (one load
 // round, fence-free hand-over): see dev_solve.hpp.
+#ifndef ICP_WAVE_STRIDE
+#define ICP_WAVE_STRIDE ((ICP_XW && ICP_BVH_THREADS > 64) ? 128 : 0)      // 1: the waves of a block come from BVH_THREADS / 64 places of the query order (hard and easy regions meet in one block: knn_walk_shared, XW)
+#endif
 #ifndef ICP_DEBUG_TIMES
 #define ICP_DEBUG_TIMES 0        // 1 (with ICP_DEBUG_STEPS=1 for the buffer): lane 0 of every wave leaves 100 MHz timestamps of its phases in dbg_steps[8 * wave ..]
 #endif
@@ -84,6 +87,17 @@ __device__ __forceinline__ void fused_front_loads(const KnnParams& kp, const Pos
     }
 }
 
+// Which 64 queries of the (Morton-sorted) order does wave w of logical block lb take?  ICP_WAVE_STRIDE 0: the block's waves are
+// neighbours; 1: they come from NW places of the order, a grid's worth of waves apart (hard and easy regions meet in one block);
+// S > 1: from NW places S waves apart (groups of S blocks share a stretch of NW * S waves; a last, partial group keeps neighbours).
+__device__ __forceinline__ int fused_wave_slot(int lb, int w, int mgrid) {
+    constexpr int NW = BVH_THREADS / WAVE, S = ICP_WAVE_STRIDE;
+    if (S == 0 || NW == 1) return lb * NW + w;
+    if (S == 1) return w * mgrid + lb;
+    const int g = lb / S, j = lb - g * S;
+    return (g + 1) * S <= mgrid ? (g * NW + w) * S + j : lb * NW + w;
+}
+
 // One correspondence, as the epilogue consumes it.
 struct PairOut { bool valid; float s0, s1, s2, d0, d1, d2, n0, n1, n2, wt; };
 
@@ -92,7 +106,7 @@ struct PairOut { bool valid; float s0, s1, s2, d0, d1, d2, n0, n1, n2, wt; };
 // (its search state was rewritten).  renewed (the persistent loop, DIM == 3): set for a lane whose query took the two-leaf tier in a wave that
 // did not walk -- `in` then holds its NEW state (anchor, bound, neighbour's record), ready to be parked again; a lane whose new state
 // cannot be given that way (no record fetched: the neighbour is past the distance threshold) leaves `searched` set instead.
-template <int DIM, bool WIDE>
+template <int DIM, bool WIDE, bool XW = false>
 __device__ __forceinline__ void fused_search_post(const KnnParams& kp, const BvhViewT<DIM>& bv, const PostParams& pp, int k, bool seeded, bool inc, const float* Pm, const float* Nm,
                                                   QueryIn<DIM>& in, uint2* __restrict__ bvh_lbq, int tid, int wave_slot, PairOut& o, bool& searched, bool* renewed = nullptr) {
     const int lane = tid & 63; (void)lane; (void)wave_slot; (void)seeded;
@@ -178,7 +192,7 @@ __device__ __forceinline__ void fused_search_post(const KnnParams& kp, const Bvh
     if (__any(need_walk)) {
         walked = true;
         float rn[3] = {rn0, rn1, rn2};
-        knn_walk_shared<DIM, BVH_THREADS, typename std::conditional<WIDE, unsigned long long, unsigned int>::type>(bv, p, rn, need_walk, best, bi, bpos, lb_others, lb3, l2, bvh_lbq, tid);
+        knn_walk_shared<DIM, BVH_THREADS, typename std::conditional<WIDE, unsigned long long, unsigned int>::type, XW ? 1 : 0>(bv, p, rn, need_walk, best, bi, bpos, lb_others, lb3, l2, bvh_lbq, tid, kp.fault);
         rn0 = rn[0]; rn1 = rn[1]; rn2 = rn[2];
         q0 = -2;                                          // the neighbour's record is read again below: it need not stay in registers while this lane helps
         // (the persistent loop: a wave that walked reloads its queries' data in the next iteration -- said here in a way the register
@@ -268,7 +282,7 @@ template <int DIM, bool WIDE, bool MERGED>      // WIDE: trees deeper than 8 lev
 __device__ __forceinline__ void fused_matcher_body(const KnnParams& kp, const BvhViewT<DIM>& bv, const int* __restrict__ qorder, const PostParams& pp, const RingParams& rp) {
     extern __shared__ uint2 bvh_lbq[];                    // [ICP_SHARE_ROWS][BVH_THREADS]: the shared walk's records; reused by the reduction
     constexpr int NW = BVH_THREADS / WAVE;
-    if constexpr (MERGED) { if ((int)blockIdx.x < rp.n_red) { ring_reduce_solve(rp); return; } }
+    if constexpr (MERGED) { if ((int)blockIdx.x < rp.n_red) { if (BVH_THREADS == RING_THREADS || threadIdx.x < RING_THREADS) ring_reduce_solve(rp); return; } }
     const int n_red = MERGED ? rp.n_red : 0;
     const int mblock = (int)blockIdx.x - n_red, mgrid = (int)gridDim.x - n_red;      // this block / the grid among the matcher blocks
     // Pose and normal matrix through the constant address space: wave-uniform and unchanged for the length of the launch (k_reduce_solve
@@ -286,28 +300,47 @@ __device__ __forceinline__ void fused_matcher_body(const KnnParams& kp, const Bv
     }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lb = xcd_contiguous_block(mblock, mgrid);                              // partial slot = logical block -> fixed summation order
-    const int t = lb * BVH_THREADS + tid;
-    const int wave_slot = lb * NW + w;
+    const int wave_slot = fused_wave_slot(lb, w, mgrid);
+    const int t = wave_slot * BVH_QPW + lane;
     ICP_STAMP(0);
-    const int k = (t < kp.n) ? (qorder ? qorder[t] : t) : -1;
+    const int k = ((BVH_QPW == WAVE || lane < BVH_QPW) && t < kp.n) ? (qorder ? qorder[t] : t) : -1;
     const bool seeded = kp.use_prev != 0, inc = kp.incremental && seeded;
     QueryIn<DIM> in;
     fused_front_loads<DIM>(kp, pp, bv, k, seeded, inc, in);
+    constexpr bool XW = xw_enabled<DIM, BVH_THREADS>();
+    if constexpr (XW) {                                   // the board of the cross-wave hand-over starts empty (LDS only: no wait for the loads above)
+        xw_init<BVH_THREADS>(bvh_lbq, tid);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     if constexpr (MERGED) { if (!ring_wait_pose(loop_slot((PoseState*)kp.ps, 0, (int)((blockIdx.x * 2u + (unsigned int)w) % (unsigned int)POSE_REPLICAS)), lane, rp.run_fault, Pm, Nm)) return; }
     PairOut o; bool searched;
-    fused_search_post<DIM, WIDE>(kp, bv, pp, k, seeded, inc, Pm, Nm, in, bvh_lbq, tid, wave_slot, o, searched);
+    fused_search_post<DIM, WIDE, XW>(kp, bv, pp, k, seeded, inc, Pm, Nm, in, bvh_lbq, tid, wave_slot, o, searched);
+    if constexpr (XW) {
+        // this wave holds its pairs; before the block's sums, it helps the waves of the block that still search (the pair waits in the
+        // wave's own LDS rows, which nobody reads once its queries are complete)
+        if (xw_block_is_searching<BVH_THREADS>(bvh_lbq)) {
+            constexpr int NT = BVH_THREADS;
+            bvh_lbq[3 * NT + tid] = make_uint2(__float_as_uint(o.s0), __float_as_uint(o.s1)); bvh_lbq[4 * NT + tid] = make_uint2(__float_as_uint(o.s2), __float_as_uint(o.d0));
+            bvh_lbq[5 * NT + tid] = make_uint2(__float_as_uint(o.d1), __float_as_uint(o.d2)); bvh_lbq[7 * NT + tid] = make_uint2(__float_as_uint(o.n0), __float_as_uint(o.n1));
+            bvh_lbq[8 * NT + tid] = make_uint2(__float_as_uint(o.n2), __float_as_uint(o.wt)); bvh_lbq[9 * NT + tid] = make_uint2(o.valid ? 1u : 0u, 0u);
+            xw_help<DIM, NT, typename std::conditional<WIDE, unsigned long long, unsigned int>::type>(bv, bvh_lbq, tid, kp.fault);
+            const uint2 a = bvh_lbq[3 * NT + tid], b = bvh_lbq[4 * NT + tid], c = bvh_lbq[5 * NT + tid], d = bvh_lbq[7 * NT + tid], e = bvh_lbq[8 * NT + tid], f = bvh_lbq[9 * NT + tid];
+            o.s0 = __uint_as_float(a.x); o.s1 = __uint_as_float(a.y); o.s2 = __uint_as_float(b.x); o.d0 = __uint_as_float(b.y); o.d1 = __uint_as_float(c.x); o.d2 = __uint_as_float(c.y);
+            o.n0 = __uint_as_float(d.x); o.n1 = __uint_as_float(d.y); o.n2 = __uint_as_float(e.x); o.wt = __uint_as_float(e.y); o.valid = f.x != 0u;
+        }
+    }
     double* partials = pp.partials;
     fused_block_epilogue(kp, pp, o, bvh_lbq, tid, wave_slot, [=](int a, double v) { partials[(size_t)a * mgrid + lb] = v; });
 }
 template <int DIM, bool WIDE>
-__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {
+__global__ __launch_bounds__(BVH_THREADS, DIM == 3 ? 6 : 4) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {
     const RingParams none{};
     fused_matcher_body<DIM, WIDE, false>(kp, bv, qorder, pp, none);
 }
 // The merged loop's launch: blocks [0, rp.n_red) = reducer of the previous iteration, the rest = this iteration's matcher (kp.ps = the
 // pose slot they wait for).
 template <int DIM, bool WIDE>
-__global__ __launch_bounds__(BVH_THREADS) void k_knn_bvh_post_ring(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp, const RingParams rp) {
-    static_assert(BVH_THREADS == RING_THREADS, "the reducer blocks share the matcher's block size");
+__global__ __launch_bounds__(BVH_THREADS, DIM == 3 ? 6 : 4) void k_knn_bvh_post_ring(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp, const RingParams rp) {
+    static_assert(BVH_THREADS >= RING_THREADS, "the reducer blocks are the first RING_THREADS threads of a matcher-sized block");
     fused_matcher_body<DIM, WIDE, true>(kp, bv, qorder, pp, rp);
 }

@@ -29,6 +29,7 @@ struct KnnParams {
     int incremental;                                         // 1: verify-and-skip with qstate (needs use_prev)
     float2* qstate2;                                         // [n] (lower bound, at the same anchor, on every target outside the neighbour's leaf and the runner-up's leaf; that second leaf as int bits, -1: none)
     int* dbg_steps;                                          // development builds (ICP_DEBUG_STEPS): [n] nodes | leaves << 16 visited by the walk of query k; nullptr otherwise
+    int* fault;                                              // fused BVH matcher: raised when a bounded wait of the cross-wave hand-over runs out (cannot happen; knn_walk_shared)
     int dbg_waves;                                           // development builds (ICP_DEBUG_TIMES): waves of the launch = where the per-query records start in dbg_steps
 };
 

@@ -288,8 +288,8 @@ __device__ __forceinline__ void loop_matcher(const LoopK<DIM>& K) {
     const LoopParams& L = K.L;
     const int tid_fixed = threadIdx.x;
     const int lb = xcd_contiguous_block((int)blockIdx.x, L.nb);            // partial slot = logical block -> fixed summation order
-    const int t = lb * BVH_THREADS + tid_fixed;
-    const int wave_slot = lb * NW + (tid_fixed >> 6); (void)wave_slot;
+    const int wave_slot = fused_wave_slot(lb, tid_fixed >> 6, L.nb);      // (the mapping of fused_matcher_body: same block partials, same sums)
+    const int t = wave_slot * BVH_QPW + (tid_fixed & 63);
     const int k_fixed = t < K.n ? t : -1;                // (sorted levels: the query index is the position)
     int q0_kept = -1;                                      // (the one carried value that stays in a register)
     bool have = false;

@@ -57,7 +57,7 @@ struct Level { DevBuf idx; DevBuf order; DevBuf sorted_idx; DevBuf pack; Cloud s
 struct Bvh {
     bool valid = false;
     int n_valid = 0, n_leaves = 0, Lp = 1;
-    DevBuf keys, keys2, vals, vals2, temp, leaves, recs, nodes, qnodes, lvl, wbox;
+    DevBuf keys, keys2, vals, vals2, temp, leaves, recs, nodes, qnodes, lvl, wbox, pos_of;
     DevBuf axl[12], side, scanr, axis_of_node;      // presorted-axes build: DIM index lists (ping-pong), side flag per point id, scan result, widest axis per node
     int n_ids = 0;                                   // size of the id space the lists index (points of the cloud the tree is built over)
     const Cloud* attrs = nullptr;                     // cloud whose normals / colours go into the records (nullptr: none)
@@ -328,6 +328,7 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
     if ((rc = ensure(c, b.vals2, (size_t)cap * 4))) return rc;
     if ((rc = ensure(c, b.leaves, (size_t)(n_slots / BVH_LEAF) * sizeof(BvhLeafT<DIM>)))) return rc;
     if ((rc = ensure(c, b.recs, (size_t)n_slots * sizeof(TgtRec)))) return rc;
+    if ((rc = ensure(c, b.pos_of, (size_t)(b.n_ids > 0 ? b.n_ids : 1) * 4))) return rc;      // position by original index (knn_walk_shared, XW)
     if ((rc = ensure(c, b.nodes, (size_t)(n_inner > 0 ? n_inner : 1) * sizeof(BvhNodeT<DIM>)))) return rc;
     if ((rc = ensure(c, b.lvl, (size_t)(b.Lp > 1 ? b.Lp / 2 : 1) * 2 * DIM * 4))) return rc;
     if ((rc = ensure(c, b.wbox, (size_t)((cap + 63) / 64) * 2 * DIM * 4))) return rc;
@@ -403,7 +404,7 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
         const bool nrm = b.attrs && b.attrs->has_normals, col = b.attrs && b.attrs->has_colors;
         hipLaunchKernelGGL(k_bvh_gather<DIM>, dim3((n_slots + 255) / 256), dim3(256), 0, c->stream, cp,
                            nrm ? b.attrs->nx.as<float>() : nullptr, nrm ? b.attrs->ny.as<float>() : nullptr, nrm ? b.attrs->nz.as<float>() : nullptr,
-                           col ? b.attrs->rgba.as<uint32_t>() : nullptr, perm, nv, n_slots, b.leaves.as<BvhLeafT<DIM>>(), b.recs.as<TgtRec>());
+                           col ? b.attrs->rgba.as<uint32_t>() : nullptr, perm, nv, n_slots, b.leaves.as<BvhLeafT<DIM>>(), b.recs.as<TgtRec>(), b.pos_of.as<int>());
     }
     for (int d = depth - 1; d >= 0; d--) {
         const int count = 1 << d, first = count - 1;
@@ -452,8 +453,8 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
     int rc;
     if (!b.valid && (rc = build_bvh<DIM>(c, b, cp))) return rc;
     BvhViewT<DIM> bv; bv.leaves = b.leaves.as<BvhLeafT<DIM>>(); bv.nodes = b.nodes.as<BvhNodeT<DIM>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
-    bv.qnodes = b.qnodes.as<BvhQuadT<DIM>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>();
-    const int nb = (n + BVH_THREADS - 1) / BVH_THREADS;
+    bv.qnodes = b.qnodes.as<BvhQuadT<DIM>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>(); bv.pos_of = b.pos_of.as<int>();
+    const int nb = fuse ? fused_nblocks(n) : (n + BVH_THREADS - 1) / BVH_THREADS;
     const size_t stack_bytes = (size_t)(ICP_SHARE_WALKS ? ICP_SHARE_ROWS : 1) * BVH_THREADS * 8;          // the shared walk's records in LDS
     if (fuse) {
         if ((rc = ensure(c, c->partials, (size_t)(nb > POST_BLOCKS ? nb : POST_BLOCKS) * NSUM * 8))) return rc;
@@ -461,7 +462,8 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
         KnnParams kf = kp; kf.out = nullptr;
         if (!c->keep_fused_records) { pp.matches = nullptr; kf.d2_out = nullptr; }     // the loop never reads the records of a fused iteration, nor the distances
         const size_t red_bytes = (size_t)(BVH_THREADS / WAVE) * 33 * 8;           // the reduction reuses the (dead) traversal stacks
-        const size_t lds = stack_bytes > red_bytes ? stack_bytes : red_bytes;
+        static const size_t lds_pad = getenv("ICP_HIP_LDS_PAD") ? (size_t)atoi(getenv("ICP_HIP_LDS_PAD")) : 0;      // development: fewer resident blocks per CU
+        const size_t lds = (stack_bytes > red_bytes ? stack_bytes : red_bytes) + xw_lds_bytes<DIM, BVH_THREADS>() + lds_pad;      // + the board of the cross-wave hand-over
         if (ml && ml->loop) {                                                      // the level's whole loop in one launch
             LoopK<DIM> K; memset(&K, 0, sizeof(K));
             // (the level's planes and the search state are packed: get_sorted_level / launch_match; anything else cannot take this path)
@@ -481,7 +483,7 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
             else hipLaunchKernelGGL((k_icp_loop<DIM, true>), dim3(nb), dim3(BVH_THREADS), lds_loop, c->stream, K);
         }
         else if (ml) {                                                             // merged loop: reducer blocks in front, pose through the ring
-            kf.ps = ml->slot; pp.ps = ml->slot; pp.partials = ml->partials;
+            kf.ps = ml->slot; pp.ps = ml->slot; pp.partials = ml->partials; kf.fault = ml->rp.run_fault;
             if (ml->ev_start) {
                 if (b.Lq <= 8) hipExtLaunchKernelGGL((k_knn_bvh_post_ring<DIM, false>), dim3(nb + ml->rp.n_red), dim3(BVH_THREADS), (uint32_t)lds, c->stream, ml->ev_start, ml->ev_stop, 0, kf, bv, order, pp, ml->rp);
                 else hipExtLaunchKernelGGL((k_knn_bvh_post_ring<DIM, true>), dim3(nb + ml->rp.n_red), dim3(BVH_THREADS), (uint32_t)lds, c->stream, ml->ev_start, ml->ev_stop, 0, kf, bv, order, pp, ml->rp);
@@ -524,7 +526,7 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr, con
     kp.tx = c->tgt.x.as<float>(); kp.ty = c->tgt.y.as<float>(); kp.tz = c->tgt.z.as<float>();
     kp.tcr = c->tgt.cr.as<float>(); kp.tcg = c->tgt.cg.as<float>(); kp.tcb = c->tgt.cb.as<float>();
     kp.mpad = c->tgt.npad; kp.ps = c->ps.as<PoseState>(); kp.pretransformed = q.pretransformed; kp.max_dist = p.max_distance;
-    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0; kp.qstate = nullptr; kp.qstate2 = nullptr; kp.incremental = 0; kp.dbg_steps = nullptr; kp.dbg_waves = 0;
+    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0; kp.qstate = nullptr; kp.qstate2 = nullptr; kp.incremental = 0; kp.dbg_steps = nullptr; kp.dbg_waves = 0; kp.fault = &c->ps.as<PoseState>()->fault;
     if (p.knn_backend == ICP_KNN_LBVH) {
         kp.nseg = 1;
         // neighbour positions and the incremental search's state in ONE allocation, sections a fixed number of elements apart
@@ -533,7 +535,7 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr, con
         kp.nn_raw = c->nn_raw.as<int>(); kp.use_prev = q.seed_prev ? 1 : 0;
 #if ICP_DEBUG_STEPS
         if ((rc = ensure(c, c->dbg_steps, (size_t)q.n * 4))) return rc;
-        kp.dbg_steps = c->dbg_steps.as<int>(); kp.dbg_waves = ((q.n + BVH_THREADS - 1) / BVH_THREADS) * (BVH_THREADS / WAVE);
+        kp.dbg_steps = c->dbg_steps.as<int>(); kp.dbg_waves = fused_nblocks(q.n) * (BVH_THREADS / WAVE);
 #endif
         if (p.knn_incremental && !q.pretransformed) {
             kp.qstate = c->qstate.as<float4>(); kp.qstate2 = c->tier2 ? c->qstate2.as<float2>() : nullptr; kp.incremental = 1;
@@ -970,7 +972,7 @@ int icp_match_seeded(icp_ctx* c, const float* poses, int32_t n_poses, icp_match_
     if (c->persist_loop && c->merge_loop && p.metric == ICP_METRIC_POINT_TO_PLANE) {
         // what icp_run launches for this configuration: k_icp_loop, all the launches' worth of iterations in ONE launch -- here with every pose
         // slot filled in up front (replica 0 of each; nobody reduces, nobody solves), the last iteration writing its records
-        const int nb = (n + BVH_THREADS - 1) / BVH_THREADS;
+        const int nb = fused_nblocks(n);
         const size_t slot_bytes = (size_t)(n_poses + 1) * POSE_REPLICAS * POSE_REPLICA_STRIDE;
         if ((rc = ensure(c, c->ring, slot_bytes + 64))) return rc;
         if ((rc = ensure(c, c->pring, (size_t)PRING_DEPTH * NSUM_USED * nb * 8))) return rc;
@@ -1133,11 +1135,11 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
         else if (p.color_icp) { if ((rc = tb.Lq <= 8 ? loop_capacity_of<6, false>(c, &cap) : loop_capacity_of<6, true>(c, &cap))) return rc; }
         else { if ((rc = tb.Lq <= 8 ? loop_capacity_of<3, false>(c, &cap) : loop_capacity_of<3, true>(c, &cap))) return rc; }
         int nbmax = 1;
-        for (int i = 0; i < iters; i++) { const int nb = (ns[i] + BVH_THREADS - 1) / BVH_THREADS; if (nb > nbmax) nbmax = nb; }
+        for (int i = 0; i < iters; i++) { const int nb = fused_nblocks(ns[i]); if (nb > nbmax) nbmax = nb; }
         for (int i = loop_from; persist && i < iters; ) {
             int j = i + 1;
             while (j < iters && clouds[j] == clouds[i] && ns[j] == ns[i] && factors[j] == factors[i]) j++;
-            const int nb = (ns[i] + BVH_THREADS - 1) / BVH_THREADS;
+            const int nb = fused_nblocks(ns[i]);
             if (nb + LOOP_RED + 1 > cap) persist = false;      // (the reducer's two-wave blocks sit in the holes the matcher grid leaves: dev_persist.hpp)
             if (nb > nbmax) nbmax = nb;
             segs.push_back(Seg{i, j});
@@ -1153,7 +1155,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
               if ((rc = ensure(c, c->partials, (size_t)(nbmax > POST_BLOCKS ? nbmax : POST_BLOCKS) * NSUM * 8))) return rc;
               if ((rc = ensure(c, c->partials2, (size_t)(nbmax > POST_BLOCKS ? nbmax : POST_BLOCKS) * NSUM * 8))) return rc; }
             size_t pring_granules = 0;
-            for (const Seg& sg : segs) pring_granules += (size_t)PRING_DEPTH * NSUM_USED * ((ns[sg.i0] + BVH_THREADS - 1) / BVH_THREADS);
+            for (const Seg& sg : segs) pring_granules += (size_t)PRING_DEPTH * NSUM_USED * (fused_nblocks(ns[sg.i0]));
             if ((rc = ensure(c, c->pring, pring_granules * 8))) return rc;
             HIPCK(c, hipMemsetAsync(c->pring.p, 0xFF, pring_granules * 8, c->stream));
             if (!c->stream2) {
@@ -1174,7 +1176,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
         static_assert(sizeof(PoseState) == 128, "a pose slot is 16 granules");
         const size_t slot_bytes = (size_t)(iters + 1) * POSE_REPLICAS * POSE_REPLICA_STRIDE, tot_bytes = (size_t)iters * NSUM * 8;
         int nbmax = POST_BLOCKS;
-        for (int i = 0; i < iters; i++) { const int nb = (ns[i] + BVH_THREADS - 1) / BVH_THREADS; if (nb > nbmax) nbmax = nb; }
+        for (int i = 0; i < iters; i++) { const int nb = fused_nblocks(ns[i]); if (nb > nbmax) nbmax = nb; }
         if ((rc = ensure(c, c->ring, slot_bytes + tot_bytes))) return rc;
         if ((rc = ensure(c, c->partials, (size_t)nbmax * NSUM * 8))) return rc;
         if ((rc = ensure(c, c->partials2, (size_t)nbmax * NSUM * 8))) return rc;
@@ -1200,7 +1202,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
         rp.run_fault = run_fault;
         if (i > 0) {
             rp.n_red = NSUM_USED;
-            rp.red_partials = ((i - 1) & 1) ? c->partials2.as<double>() : c->partials.as<double>(); rp.red_nblocks = (ns[i - 1] + BVH_THREADS - 1) / BVH_THREADS;
+            rp.red_partials = ((i - 1) & 1) ? c->partials2.as<double>() : c->partials.as<double>(); rp.red_nblocks = fused_nblocks(ns[i - 1]);
             rp.totals_row = trows + (size_t)(i - 1) * NSUM; rp.ps_in = loop_slot(slots, i - 1, 0); rp.ps_out = loop_slot(slots, i, 0);
             rp.stats = c->stats.as<icp_iter_stats>() + (i - 1); rp.n_src = ns[i - 1];
             if (i == iters) rp.final_out = (PoseState*)(c->stats.as<char>() + stats_pad);
@@ -1253,7 +1255,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
         HIPCK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
         size_t pring_off = 0;
         for (const Seg& sg : segs) {
-            const int i = sg.i0, nb = (ns[i] + BVH_THREADS - 1) / BVH_THREADS;
+            const int i = sg.i0, nb = fused_nblocks(ns[i]);
             LoopParams L; memset(&L, 0, sizeof(L));
             L.iters = sg.i1 - sg.i0; L.first = i; L.seed_first = (i > 0 && i == loop_from && factors[i] == factors[i - 1] && ns[i - 1] == ns[i] && clouds[i] == clouds[i - 1]) ? 1 : 0; L.slots = slots; L.totals = trows; L.pring = c->pring.as<unsigned long long>() + pring_off; L.nb = nb;
             { const char* e = getenv("ICP_HIP_LOOP_PRESLEEP"); L.presleep_eighths = e ? atoi(e) : 5; }
@@ -1490,7 +1492,7 @@ int icp_estimate_normals(icp_ctx* c, const float* xyz, int32_t n, int32_t k, con
     CoordPtrs<3> cp; cp.c[0] = cl.x.as<float>(); cp.c[1] = cl.y.as<float>(); cp.c[2] = cl.z.as<float>();
     if ((rc = build_bvh<3>(c, b, cp))) return rc;
     BvhViewT<3> bv; bv.leaves = b.leaves.as<BvhLeafT<3>>(); bv.nodes = b.nodes.as<BvhNodeT<3>>(); bv.n_valid = b.n_valid; bv.Lp = b.Lp; bv.tgt = cp;
-    bv.qnodes = b.qnodes.as<BvhQuadT<3>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>();
+    bv.qnodes = b.qnodes.as<BvhQuadT<3>>(); bv.Lq = b.Lq; bv.recs = b.recs.as<TgtRec>(); bv.pos_of = b.pos_of.as<int>();
     int depth = 0; while ((1 << depth) < b.Lp) depth++;
     if ((rc = ensure(c, c->staging, (size_t)n * 16))) return rc;
     float* d_n = c->staging.as<float>(); float* d_c = d_n + (size_t)n * 3;

@@ -12,7 +12,8 @@ c = binding.Context(0)
 c.params.max_distance = 10.0; c.params.metric = 1; c.params.knn_backend = 1
 c.set_stage_timing(0)
 c.push_params(); c.set_target(p["tgt_pts"], p["tgt_nrm"]); c.set_source(p["src_pts"], p["src_nrm"])
-nw = ((n + 127) // 128) * 2
+BT = int(os.environ.get('ICP_DEV_BVH_THREADS', '256'))       # threads per block of the library under test
+nw = ((n + BT - 1) // BT) * (BT // 64)
 for iters in [int(a) for a in sys.argv[1:]] or [1, 3, 6, 12, 45]:
     c.params.n_iterations = iters; c.push_params()
     c.run(np.eye(4))
@@ -51,7 +52,7 @@ for iters in [int(a) for a in sys.argv[1:]] or [1, 3, 6, 12, 45]:
     xc = simd // 4096
     print("  per XCD as placed by the hardware: " + "  ".join("x%d: %d waves, mean end %.1f, last %.1f" % (x, (xc == x).sum(), rel[xc == x, 5].mean(), rel[xc == x, 5].max()) for x in np.unique(xc)))
     if os.environ.get("ICP_DEV_PLACEMENT"):                # how does the dispatcher place consecutive hardware blocks?  (XCD, CU) of blocks 0, 8, 16, ... (the ones XCD 0 gets)
-        nbk = nw // 2; CHK = 16; fullk = nbk // (8 * CHK) * (8 * CHK)
+        nbk = nw // (BT // 64); CHK = 16; fullk = nbk // (8 * CHK) * (8 * CHK)
         def logical(b):
             if b >= fullk: return b
             x, j = b & 7, b >> 3
@@ -61,9 +62,9 @@ for iters in [int(a) for a in sys.argv[1:]] or [1, 3, 6, 12, 45]:
         seq1 = [(int(simd[2 * logical(b)] // 4096), int((simd[2 * logical(b)] // 4) % 1024)) for b in range(0, 24)]
         print("  placement of hardware blocks 0..23: " + " ".join("%d:%d" % s_ for s_ in seq1))
     # which XCD ran which logical block (xcd_contiguous_block with ICP_XCD_CHUNK = 16): is one of them the tail?
-    nb = nw // 2; CH = 16; full = nb // (8 * CH) * (8 * CH)
-    lbs = np.arange(nb); xcd = np.where(lbs < full, (lbs // CH) % 8, lbs % 8)
-    wx = np.repeat(xcd, 2)
+    NWB = BT // 64; nb = nw // NWB; CH = 16; full = nb // (8 * CH) * (8 * CH)
+    lbs = np.arange(nw) % nb if os.environ.get('ICP_DEV_STRIDE', '1') == '1' and NWB > 1 else np.arange(nw) // NWB      # logical block of every wave slot
+    wx = np.where(lbs < full, (lbs // CH) % 8, lbs % 8)
     print("  per XCD: " + "  ".join("x%d: end mean %.1f max %.1f, walk-us sum %.0f" % (x, rel[wx == x, 5].mean(), rel[wx == x, 5].max(), (rel[wx == x, 2] - rel[wx == x, 1]).sum()) for x in range(8)))
     last = np.argsort(rel[:, 5])[-5:]
     for i in last: print("   late wave %5d: walkers %2d  stamps %s" % (i, walkers[i], np.round(rel[i], 2)))
