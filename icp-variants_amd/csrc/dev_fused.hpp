@@ -37,7 +37,7 @@ struct P2pGen {                                           // values 0..21 = sum 
 #define ICP_WAVE_STRIDE ((ICP_XW && ICP_BVH_THREADS > 64) ? 128 : 0)      // 1: the waves of a block come from BVH_THREADS / 64 places of the query order (hard and easy regions meet in one block: knn_walk_shared, XW)
 #endif
 #ifndef ICP_DEBUG_TIMES
-#define ICP_DEBUG_TIMES 0        // 1 (with ICP_DEBUG_STEPS=1 for the buffer): lane 0 of every wave leaves 100 MHz timestamps of its phases in dbg_steps[8 * wave ..]
+#define ICP_DEBUG_TIMES 0        // (default set in dev_solve.hpp) 1 (with ICP_DEBUG_STEPS=1 for the buffer): lane 0 of every wave leaves 100 MHz timestamps of its phases in dbg_steps[8 * wave ..]
 #endif
 #if ICP_DEBUG_TIMES
 #define ICP_STAMP(j) do { if (kp.dbg_steps && lane == 0) kp.dbg_steps[8 * (wave_slot) + (j)] = (int)(unsigned int)wall_clock64(); } while (0)

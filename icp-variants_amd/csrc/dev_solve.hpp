@@ -262,59 +262,79 @@ struct SolveParams {
 // p2plane_lanes_core: m = the 27 point-to-plane sums (shared memory), pose_in = the pose the iteration searched at (16 floats, global or
 // shared).  Returns the composed pose dT * pose_in (16 floats in shared memory, valid for every thread after the call) or nullptr when
 // a pivot fails the rank test (nothing computed).  All threads of the block must call it (>= 64 threads).
+// One wave does it: its LDS operations execute in program order, so the hand-overs between its lanes need no workgroup barrier -- only
+// the compiler must keep the order (wave_sync).  Measured in the merged launch (tools/dev_ring_times.py): 2.8 us with twelve block barriers,
+// six sequential divisions in the back substitution and the rotation composed by one thread.
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ const float* p2plane_lanes_core(const double* m /* shared */, const float* pose_in) {
-    __shared__ double A[6][7], Lm[6][6], od[6], xs[6];
-    __shared__ float scs[6], dTs[16], npose[16];
+    __shared__ double A[6][7], Lm[6][6], od[6], zs[6];
+    __shared__ float npose[16];
     __shared__ int okflag;
-    const int tid = threadIdx.x, i = tid / 7, j = tid % 7;
-    if (tid < 42) A[i][j] = (j == 6) ? m[21 + i] : (j >= i ? m[i * 6 - i * (i - 1) / 2 + (j - i)] : 0.0);
-    if (tid < 6) od[tid] = m[tid * 6 - tid * (tid - 1) / 2];
-    if (tid == 0) okflag = 1;
-    __syncthreads();
-    for (int k = 0; k < 6; k++) {
-        const double d = A[k][k];
-        const bool ok = (d > 1e-9 * od[k]) && (k > 0 || od[0] > 0);          // solve_ldlt6's pivot tests
-        if (!ok) { okflag = 0; break; }                                       // every thread sees the same values
-        if (tid < 42 && i > k && j >= i) {
-            const double lik = A[k][i] / d;
-            if (j == i) Lm[i][k] = lik;
-            A[i][j] = A[i][j] - lik * A[k][j];
+    const int tid = threadIdx.x;
+    if (tid < WAVE) {
+        const int i = tid / 7, j = tid % 7;
+        if (tid < 42) A[i][j] = (j == 6) ? m[21 + i] : (j >= i ? m[i * 6 - i * (i - 1) / 2 + (j - i)] : 0.0);
+        if (tid < 6) od[tid] = m[tid * 6 - tid * (tid - 1) / 2];
+        wave_sync();
+        bool ok_all = true;
+        for (int k = 0; k < 6; k++) {
+            const double d = A[k][k];
+            const bool ok = (d > 1e-9 * od[k]) && (k > 0 || od[0] > 0);          // solve_ldlt6's pivot tests
+            if (!ok) { ok_all = false; break; }                                   // every lane sees the same values
+            if (tid < 42 && i > k && j >= i) {
+                const double lik = A[k][i] / d;
+                if (j == i) Lm[i][k] = lik;
+                A[i][j] = A[i][j] - lik * A[k][j];
+            }
+            wave_sync();
         }
-        __syncthreads();
+        if (tid == 0) okflag = ok_all ? 1 : 0;
+        if (ok_all) {
+            if (tid < 6) zs[tid] = A[tid][6] / A[tid][tid];                      // D y = z: the six quotients side by side ...
+            wave_sync();
+            // ... L^T x = y: the same subtractions in the same order as ever, by EVERY lane for itself (a wave pays per instruction, not per
+            // lane: what all lanes hold in registers needs no further trip through LDS -- each of those costs more than the arithmetic
+            // between two of them)
+            double x[6];
+#pragma unroll
+            for (int r = 5; r >= 0; r--) {
+                double v = zs[r];
+#pragma unroll
+                for (int c = r + 1; c < 6; c++) v = v - Lm[c][r] * x[c];
+                x[r] = v;
+            }
+            // angles -> sines and cosines: lanes 0..2 take one angle each, the six values travel as scalars (ICPOptimizer.h:768)
+            const float ang = (float)(tid == 0 ? x[0] : tid == 1 ? x[1] : x[2]);
+            double sd, cd;
+            sincos((double)ang, &sd, &cd);
+            const float sf = (float)sd, cf = (float)cd;
+            const float ca = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cf), 0)), sa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sf), 0));
+            const float cb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cf), 1)), sb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sf), 1));
+            const float cg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cf), 2)), sg = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sf), 2));
+            if (tid < 16) {
+                // entry (r, c) of dT * pose, dT = [Rx Ry Rz | t] (:771-773, set_pose_f32, mat4_mul_f32): row r of the two 3 x 3 products with
+                // mat3_mul_f32's operation order, in registers
+                const int c = tid >> 2, r = tid & 3;
+                const float one = 1.f, zero = 0.f;
+                const float rx0 = r == 0 ? one : zero, rx1 = r == 1 ? ca : r == 2 ? sa : zero, rx2 = r == 1 ? -sa : r == 2 ? ca : zero;      // row r of Rx
+                const float ry[9] = {cb, zero, sb, zero, one, zero, -sb, zero, cb}, rz[9] = {cg, -sg, zero, sg, cg, zero, zero, zero, one};
+                float q[3], rr[3];
+#pragma unroll
+                for (int e = 0; e < 3; e++) q[e] = rx0 * ry[e] + (rx1 * ry[3 + e] + rx2 * ry[6 + e]);
+#pragma unroll
+                for (int e = 0; e < 3; e++) rr[e] = q[0] * rz[e] + (q[1] * rz[3 + e] + q[2] * rz[6 + e]);
+                const float tr = (float)(r == 0 ? x[3] : r == 1 ? x[4] : x[5]);
+                const float d0 = r < 3 ? rr[0] : zero, d1 = r < 3 ? rr[1] : zero, d2 = r < 3 ? rr[2] : zero, d3 = r < 3 ? tr : one;      // row r of dT
+                float acc = d0 * pose_in[c * 4 + 0];                               // mat4_mul_f32(dT, pose): column-major, sequential over k
+                acc = acc + d1 * pose_in[c * 4 + 1];
+                acc = acc + d2 * pose_in[c * 4 + 2];
+                acc = acc + d3 * pose_in[c * 4 + 3];
+                npose[tid] = acc;
+            }
+        }
     }
     __syncthreads();
     if (!okflag) return nullptr;
-    if (tid == 0) {
-        double x[6];
-        for (int r = 5; r >= 0; r--) {                   // D y = z ; L^T x = y
-            double v = A[r][6] / A[r][r];
-            for (int c = r + 1; c < 6; c++) v = v - Lm[c][r] * x[c];
-            x[r] = v;
-        }
-        for (int r = 0; r < 6; r++) xs[r] = x[r];
-    }
-    __syncthreads();
-    if (tid < 3) { const float ang = (float)xs[tid]; scs[2 * tid] = (float)cos((double)ang); scs[2 * tid + 1] = (float)sin((double)ang); }   // ICPOptimizer.h:768
-    __syncthreads();
-    if (tid == 0) {
-        const float ca = scs[0], sa = scs[1], cb = scs[2], sb = scs[3], cg = scs[4], sg = scs[5];
-        const float Rx[9] = {1, 0, 0, 0, ca, -sa, 0, sa, ca}, Ry[9] = {cb, 0, sb, 0, 1, 0, -sb, 0, cb}, Rz[9] = {cg, -sg, 0, sg, cg, 0, 0, 0, 1};
-        float Rxy[9], R[9], dT[16];
-        mat3_mul_f32(Rx, Ry, Rxy); mat3_mul_f32(Rxy, Rz, R);                   // :771-773
-        const float t[3] = {(float)xs[3], (float)xs[4], (float)xs[5]};
-        set_pose_f32(dT, R, t);
-        for (int q = 0; q < 16; q++) dTs[q] = dT[q];
-    }
-    __syncthreads();
-    if (tid < 16) {                                       // mat4_mul_f32(dT, pose): column-major, sequential over k
-        const int c = tid >> 2, r = tid & 3;
-        float acc = dTs[0 * 4 + r] * pose_in[c * 4 + 0];
-        acc = acc + dTs[1 * 4 + r] * pose_in[c * 4 + 1];
-        acc = acc + dTs[2 * 4 + r] * pose_in[c * 4 + 2];
-        acc = acc + dTs[3 * 4 + r] * pose_in[c * 4 + 3];
-        npose[tid] = acc;
-    }
-    __syncthreads();
     return npose;
 }
 // The k_reduce_solve form: pose state updated in place.  Returns false (nothing written) when the fast path does not apply: other
@@ -325,14 +345,13 @@ __device__ __forceinline__ bool solve_p2plane_lanes(const SolveParams& sp, const
     const float* npose = p2plane_lanes_core(tot + SUM_M, ps->pose);
     if (!npose) return false;
     const int tid = threadIdx.x;
-    if (tid == 0) {
-        if (sp.sums_out) for (int a = 0; a < NSUM; a++) sp.sums_out[a] = tot[a];
-        // means are not needed for this metric; keep the state defined (k_reduce_solve's phase 0 writes them too)
-        const double n = tot[SUM_N];
-        for (int k = 0; k < 3; k++) { ps->mean_s[k] = (float)(tot[SUM_S + k] / n); ps->mean_d[k] = (float)(tot[SUM_D + k] / n); }
+    if (tid == 0 && sp.sums_out) for (int a = 0; a < NSUM; a++) sp.sums_out[a] = tot[a];
+    if (tid >= 64 && tid < 70) {                           // means are not needed for this metric; keep the state defined (k_reduce_solve's phase 0 writes them too): six lanes, one quotient each
+        const int k = tid - 64; const double n = tot[SUM_N];
+        if (k < 3) ps->mean_s[k] = (float)(tot[SUM_S + k] / n); else ps->mean_d[k - 3] = (float)(tot[SUM_D + k - 3] / n);
     }
     if (tid < 16) { ps->pose[tid] = npose[tid]; if (sp.stats) sp.stats->pose[tid] = npose[tid]; }
-    if (tid == 32) normal_matrix_from_pose(npose, ps->nmat);
+    if (tid >= 32 && tid < 41) ps->nmat[tid - 32] = normal_matrix_entry(npose, tid - 32);      // nine lanes, one quotient each
     if (tid == 33 && sp.stats) {
         sp.stats->n_src = sp.n_src; sp.stats->n_valid = (int)tot[SUM_N];
         sp.stats->rmse = -1.f; sp.stats->benchmark_error = -1.f; sp.stats->status = ICP_OK;
@@ -601,12 +620,24 @@ __device__ __forceinline__ unsigned long long granule_of(unsigned int lo, unsign
 // shuffle trees, the four wave sums added in the same order -- so the merged loop and the separate launches give bit-identical poses
 // (tests/test_gpu_merged.py compares them).
 constexpr int RING_THREADS = 128;
+#ifndef ICP_DEBUG_TIMES
+#define ICP_DEBUG_TIMES 0
+#endif
+#if ICP_DEBUG_TIMES
+// development builds: thread 0 of reducer block a stamps the 100 MHz clock at [8 a + j]: j = 0 block start, 1 folded, 2 total published;
+// block 0 also at [8 NSUM_USED + j]: 0 totals received, 1 solved, 2 pose published  (icp_debug_ring_times; the stamps of the last matcher launch of a run stay: the closing launch does not stamp)
+__device__ int g_ring_dbg[(NSUM_USED + 1) * 8];
+#define RING_STAMP(a, j) do { if (threadIdx.x == 0 && !rp.final_out) g_ring_dbg[8 * (a) + (j)] = (int)(unsigned int)wall_clock64(); } while (0)
+#else
+#define RING_STAMP(a, j)
+#endif
 __device__ __forceinline__ void ring_reduce_solve(const RingParams& rp) {
     __shared__ double tot[NSUM];
     __shared__ double wsum[4];
     __shared__ unsigned int slot_words[32];
     __shared__ int give_up;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, a = blockIdx.x;
+    RING_STAMP(a, 0);
     if (a == 0 && rp.ps_in->fault) {                      // the chain was cut further up: pass it on, touch nothing else
         { const unsigned int* src = (const unsigned int*)rp.ps_in; for (int q = tid; q < 16 * POSE_REPLICAS; q += RING_THREADS) __hip_atomic_store((unsigned long long*)loop_slot(rp.ps_out, 0, q >> 4) + (q & 15), granule_of(src[2 * (q & 15)], src[2 * (q & 15) + 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (rp.final_out && tid < 32) ((unsigned int*)rp.final_out)[tid] = src[tid]; }
@@ -633,6 +664,7 @@ __device__ __forceinline__ void ring_reduce_solve(const RingParams& rp) {
         for (int off = 32; off > 0; off >>= 1) { x0 += __shfl_down(x0, off, WAVE); x1 += __shfl_down(x1, off, WAVE); }
         if (lane == 0) { wsum[w] = x0; wsum[2 + w] = x1; }
     }
+    RING_STAMP(a, 1);
     __syncthreads();
     if (tid == 0) {
         double x = wsum[0];
@@ -640,6 +672,7 @@ __device__ __forceinline__ void ring_reduce_solve(const RingParams& rp) {
         const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
         __hip_atomic_store(rp.totals_row + a, granule_of((unsigned int)bits, (unsigned int)(bits >> 32)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    RING_STAMP(a, 2);
     if (a != 0) return;
     if (tid == 0) give_up = 0;
     __syncthreads();
@@ -658,6 +691,7 @@ __device__ __forceinline__ void ring_reduce_solve(const RingParams& rp) {
         tot[tid] = v;
     }
     __syncthreads();
+    RING_STAMP(NSUM_USED, 0);
     const PoseState* pin = rp.ps_in;
     const double n = tot[SUM_N];
     int fault = 0, status = ICP_OK;
@@ -665,23 +699,19 @@ __device__ __forceinline__ void ring_reduce_solve(const RingParams& rp) {
     if (give_up) { fault = 1; if (tid == 0) atomicOr(rp.run_fault, 1); }
     else if (n > 0) { npose = p2plane_lanes_core(tot + SUM_M, pin->pose); if (!npose) fault = 2; }      // (uniform: every thread of the block takes the same branch)
     else status = ICP_ERR_NO_CORRESPONDENCES;              // the pose stays (ICPOptimizer.h:668,680: the reference would hang in ASSERT)
+    RING_STAMP(NSUM_USED, 1);
     // the slot: pose, normal matrix, means, fault -- assembled in LDS, published as 16 granules
     if (tid < 16) slot_words[tid] = __float_as_uint(npose ? npose[tid] : pin->pose[tid]);
-    if (tid == 32) {
-        float nm[9];
-        if (npose) normal_matrix_from_pose(npose, nm); else for (int q = 0; q < 9; q++) nm[q] = pin->nmat[q];
-        for (int q = 0; q < 9; q++) slot_words[16 + q] = __float_as_uint(nm[q]);
+    if (tid >= 32 && tid < 41) slot_words[16 + tid - 32] = __float_as_uint(npose ? normal_matrix_entry(npose, tid - 32) : pin->nmat[tid - 32]);      // nine lanes, one quotient each
+    if (tid >= 64 && tid < 70) {                           // the means of the valid pairs (symmetric ICP reads them; kept defined here): six lanes, one quotient each
+        const int k = tid - 64;
+        slot_words[25 + k] = __float_as_uint(n > 0 ? (float)(tot[(k < 3 ? SUM_S : SUM_D - 3) + k] / n) : 0.f);
     }
-    if (tid == 33) {
-        for (int k = 0; k < 3; k++) {
-            slot_words[25 + k] = __float_as_uint(n > 0 ? (float)(tot[SUM_S + k] / n) : 0.f);
-            slot_words[28 + k] = __float_as_uint(n > 0 ? (float)(tot[SUM_D + k] / n) : 0.f);
-        }
-        slot_words[31] = (unsigned int)fault;
-    }
+    if (tid == 70) slot_words[31] = (unsigned int)fault;
     __syncthreads();
     for (int q = tid; q < 16 * POSE_REPLICAS; q += RING_THREADS)      // every replica of the slot, 16 granules each
         __hip_atomic_store((unsigned long long*)loop_slot(rp.ps_out, 0, q >> 4) + (q & 15), granule_of(slot_words[2 * (q & 15)], slot_words[2 * (q & 15) + 1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    RING_STAMP(NSUM_USED, 2);
     if (rp.final_out && tid < 32) ((unsigned int*)rp.final_out)[tid] = slot_words[tid];
     if (rp.stats && !fault) {                             // the record of the reduced iteration (read by the host after the run)
         if (tid < 16) rp.stats->pose[tid] = __uint_as_float(slot_words[tid]);

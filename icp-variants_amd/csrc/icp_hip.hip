@@ -1544,6 +1544,18 @@ int icp_debug_steps(icp_ctx* c, int32_t* out, int32_t n) {
 //                               separate k_reduce_solve launches (rank-deficient system, or a bounded wait that ran out).
 //   icp_debug_poison_handover : leaves a stale, valid-looking total in slot `slot` of k_reduce_solve's hand-over area -- what a run cut
 //                               short between a block's publish and block 0's re-arm would leave behind.  The next call must not see it.
+int icp_debug_ring_times(icp_ctx* c, int32_t* out, int32_t n) {     // development builds (ICP_DEBUG_TIMES): the reducer blocks' clock stamps of the last merged launch
+#if ICP_DEBUG_TIMES
+    if (!c || !out || n < (NSUM_USED + 1) * 8) return ICP_ERR_INVALID_ARG;
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    HIPCK(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(icpdev::g_ring_dbg), (size_t)(NSUM_USED + 1) * 8 * 4));
+    return ICP_OK;
+#else
+    (void)c; (void)out; (void)n;
+    return ICP_ERR_INVALID_ARG;
+#endif
+}
 int icp_debug_counters(icp_ctx* c, int32_t* merged_runs, int32_t* merged_fallbacks) {
     if (!c) return ICP_ERR_INVALID_ARG;
     if (merged_runs) *merged_runs = c->merged_runs + c->loop_runs;
