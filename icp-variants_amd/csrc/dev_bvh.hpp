@@ -798,12 +798,47 @@ __device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, cons
 #define ICP_XW_SLEEP 4
 #endif
 constexpr int XW_SLOTS = 64, XW_CTRL = 32;
-constexpr int XW_INTS = XW_CTRL + XW_SLOTS * 6;          // control words, slot states, items (2 x uint2 + int per slot)
+// ---- ... and between the BLOCKS of the launch (GX) -------------------------------------------------------------------------------
+// What remains after XW is the imbalance between CUs: a CU holds 5 or 6 blocks for the whole launch and their costs do not average out
+// (iteration 2: the mean CU is done at 64 us, the last at 85).  A block whose waves walk for long POSTS parked subtrees in its own
+// outbox in global memory (GX_SLOTS slots of 16 eight-byte granules, each granule self-validating like the pose hand-over: written
+// once by a write-through store, all-ones = not there yet); wave 0 of a block that is finished with everything (its partial is stored)
+// probes the outboxes of other blocks, claims a posted slot (compare-and-swap on the slot's claim word: 1 posted -> 2 claimed),
+// searches the subtree with its 64 lanes like a query of its own (knn_walk_shared, MODE 3) and writes the result -- winner, runner-up
+// entry, bound on the rest, smallest skipped bound, position -- into the slot's result granules.  The owner block folds that result
+// into the query's record like the result of one of its own lanes (the slot counts in out[] of the owner's wave until then), takes
+// back what nobody claimed (claim 1 -> 3), and leaves every slot it used as it found it: nothing to re-arm between launches.
+//   slot granules: 0 (owner thread | level << 16, node)  1 (best, index)  2 (position, p.x)  3 (p.y, p.z)  4 claim word
+//                  5 (index, best) of the winner  6 runner-up entry (leaf, distance)  7 (rest, skipped)  8 (position, 1)
+// MEASURED AND NOT ADOPTED (round 3; compiled out, -DICP_GX=1 builds it, ICP_HIP_GX=0 switches it off at run time): exact -- the whole
+// GPU suite passes with it -- but slower: 32.6 k against 33.3 k iterations/s with it switched off in the same binary, and that binary is
+// itself 2.5 % behind the one without the code (34.1 k): the extra paths raise the walk's natural register demand from 74-78 to 85-89,
+// which the 80-register budget turns into 28-44 bytes of scratch.  What the counters said (tools/dev_gx_counts.py): waves pass the
+// posting threshold (16 passes of the hand-over loop) almost only in iteration 0; there 2 100 subtrees are posted, 260 claimed by helpers,
+// 1 840 taken back by their owners; a helper needs a dozen probe rounds of 2-3 us to come across one of the ~ 60 posting blocks among
+// 1 448.  To make it pay it would need: a posting criterion in TIME (waves still walking past the launch's mean), a list of the posting
+// blocks instead of probing, and 10 registers.
+#ifndef ICP_GX
+#define ICP_GX 0
+#endif
+constexpr int GX_SLOTS = 32, GX_GRANULES = 16;
+constexpr unsigned long long GX_EMPTY = ~0ull;
+#if defined(ICP_DEBUG_TIMES) && ICP_DEBUG_TIMES
+__device__ unsigned int g_gx_dbg[16];    // development builds: 0 posted, 1 claimed by helpers, 2 taken back, 3 results folded, 4 helper waves, 5 helper rounds, 6 helper rounds with a claim
+#define GX_COUNT(i, n) atomicAdd(&g_gx_dbg[i], (unsigned int)(n))
+#else
+#define GX_COUNT(i, n)
+#endif
+constexpr int XW_INTS = XW_CTRL + XW_SLOTS + GX_SLOTS + XW_SLOTS * 5 + GX_SLOTS * 5;      // control words, slot states (board, outbox), items (2 x uint2 + int per slot), shadow of the posted items
 constexpr int XW_SPIN_LIMIT = 1 << 22;                   // polls of an idle wave (~0.3 us each) before it gives up and raises the fault word
 template <int DIM, int NT> constexpr bool xw_enabled() { return ICP_XW && DIM == 3 && NT > WAVE && NT / WAVE <= 8; }
 template <int DIM, int NT> constexpr size_t xw_lds_bytes() { return xw_enabled<DIM, NT>() ? (size_t)XW_INTS * 4 : 0; }
 // (block start, before the first __syncthreads of the kernel: thread t clears word t of the control block and the slot states)
-template <int NT> __device__ __forceinline__ void xw_init(uint2* lbq, int tid) { if (tid < XW_CTRL + XW_SLOTS) ((int*)(lbq + ICP_SHARE_ROWS * NT))[tid] = 0; }
+template <int NT> __device__ __forceinline__ void xw_init(uint2* lbq, int tid) { if (tid < XW_CTRL + XW_SLOTS + GX_SLOTS) ((int*)(lbq + ICP_SHARE_ROWS * NT))[tid] = 0; }
+// sc1 (write-through / L1-bypassing) accesses to the outboxes
+__device__ __forceinline__ void gx_store(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long gx_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long gx_pack(unsigned int lo, unsigned int hi) { const unsigned long long g = ((unsigned long long)hi << 32) | lo; return g == GX_EMPTY ? g ^ 1ull : g; }
 // is any wave of this block searching right now?  (a wave without walkers of its own asks once)
 template <int NT> __device__ __forceinline__ bool xw_block_is_searching(uint2* lbq) {
     const int* xc = (const int*)(lbq + ICP_SHARE_ROWS * NT);
@@ -812,18 +847,23 @@ template <int NT> __device__ __forceinline__ bool xw_block_is_searching(uint2* l
 }
 
 // MODE 0: the wave on its own; 1: XW, the wave's own walks (it leaves when its queries are complete, and takes items off the board while it
-// waits for parts of them that other waves hold); 2: XW, help only (xw_help: no queries of its own, rows 3.. of the wave untouched).
+// waits for parts of them that other waves hold); 2: XW, help only (xw_help: no queries of its own, rows 3.. of the wave untouched);
+// 3: GX helper (gx_help): the wave on its own, lane by lane a SUBTREE (start_L, start_idx) of somebody else's query with that query's
+// running best as the seed; the results come back raw -- best / bi / bpos = the winner, lb_others / l2o = the runner-up entry (squared
+// distance, leaf), lb3 = the bound on the rest (squared), keep3[0] = the smallest skipped box bound (squared).
 template <int DIM, int NT, class MaskT, int MODE = 0>
 __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* p, float* keep3, bool need_walk, float& best, int& bi, int& bpos, float& lb_others, float& lb3, int& l2o,
-                                                uint2* __restrict__ lbq, int tid, int* fault = nullptr) {
-    constexpr bool XW = MODE != 0, HELP = MODE == 2;
+                                                uint2* __restrict__ lbq, int tid, int* fault = nullptr, const GxParams* gx = nullptr, int gx_block = 0, int start_L = 0, int start_idx = 0) {
+    constexpr bool XW = MODE == 1 || MODE == 2, HELP = MODE == 2, PROXY = MODE == 3;
+    const bool GXON = ICP_GX && XW && gx && gx->slots;                    // (uniform) this launch posts to / collects from the block's outbox
     static_assert(!XW || xw_enabled<DIM, NT>(), "cross-wave sharing: DIM 3, 2..8 waves per block");
     const int lane = tid & 63, Lq = bv.Lq, wbase = tid & ~63, myw = tid >> 6;
     uint2* R = lbq + wbase;                                               // this wave's columns of the rows
     constexpr unsigned int FMAXB = 0x7F7FFFFFu, NONE = 0x7F800000u;
     unsigned long long* keys = (unsigned long long*)lbq;                  // keys[t]: row 0 of thread t (block-wide: an owner may sit in another wave)
     int* xc = (int*)(lbq + ICP_SHARE_ROWS * NT);                          // XW: nreg, ndone, idlew, -, out[8], helped[8], ...
-    int* xstate = xc + XW_CTRL; uint2* xa = (uint2*)(xstate + XW_SLOTS); uint2* xb = xa + XW_SLOTS; int* xp = (int*)(xb + XW_SLOTS);
+    int* xstate = xc + XW_CTRL; int* gstate = xstate + XW_SLOTS; uint2* xa = (uint2*)(gstate + GX_SLOTS); uint2* xb = xa + XW_SLOTS; int* xp = (int*)(xb + XW_SLOTS);
+    uint2* ga = (uint2*)(xp + XW_SLOTS); uint2* gb = ga + GX_SLOTS; int* gp = (int*)(gb + GX_SLOTS);      // GX: what this block posted (the owner takes it back from here)
     if (!HELP) {
         R[3 * NT + lane] = make_uint2(__float_as_uint(best), (unsigned int)bi);
         R[4 * NT + lane] = make_uint2((unsigned int)bpos, __float_as_uint(lb_others));
@@ -861,12 +901,12 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
     const unsigned long long wm = __ballot(need_walk);
     const int W = __popcll(wm);
     if (MODE == 1 && lane == 0) __hip_atomic_fetch_add(xc + 0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // nreg: this wave has queries that search
-    const bool spread = !HELP && ICP_SHARE_SPREAD && Lq > 0 && W > 0 && W * (Lq + 1) <= WAVE && wm == __ballot(need_walk && wp >= 0);
+    const bool spread = !HELP && !PROXY && ICP_SHARE_SPREAD && Lq > 0 && W > 0 && W * (Lq + 1) <= WAVE && wm == __ballot(need_walk && wp >= 0);
     if (ICP_PREFETCH_PATH && !spread && need_walk && wp >= 0) touched = quad_prefetch_path<DIM>(bv, wp >> 3);
     float b2 = FLT_MAX, b3 = FLT_MAX; int l2 = -1;
     unsigned int mlb = FMAXB;
     int owner = need_walk ? tid : -1;                                     // whose query this lane is searching for (thread of the block); -1: idle
-    QuadStateT<MaskT> st; st.L = 0; st.idx = 0; st.pending = 0; st.alive = need_walk;
+    QuadStateT<MaskT> st; st.L = PROXY ? start_L : 0; st.idx = PROXY ? start_idx : 0; st.pending = 0; st.alive = need_walk;
     float thr = fminf(wb * ICP_PRUNE_SLACK, FLT_MAX);
     // one node step on the child bounds of node (st.L, st.idx): nearest surviving child next, the other survivors parked
     auto descend = [&](const f2& l01, const f2& l23) {
@@ -910,8 +950,9 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
         if (need_walk) { st.L = Lq; st.idx = wp >> 3; }                   // the walker itself: straight to the seed's leaf
     }
     bool polling = false;                                                 // XW, wave-uniform: this wave is counted in idlew
-    int polls = 0;
+    int polls = 0, trips = 0;
     for (;;) {
+        trips++;
         if (!st.alive && owner >= 0) {
             // this lane's (part of the) search is over: fold it into the owner's record.  Winner: 64-bit minimum of (distance, index).
             // Runner-up entry (distance, leaf): 64-bit minimum as well; whatever loses there -- and is not in the same leaf as what beat
@@ -961,7 +1002,50 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
                 thr = fminf(wb * ICP_PRUNE_SLACK, FLT_MAX);
                 st.L = (int)(ia.x >> 16); st.idx = (int)ia.y; st.pending = 0; st.alive = true;
             }
-            if (__any(mine)) {
+            bool gmine = false;
+            if (ICP_GX && XW && GXON && !complete && !__any(mine) && __builtin_amdgcn_readfirstlane(__hip_atomic_load(xc + 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) > 0) {
+                // GX: what this block posted -- lane i looks at slot i.  A result that has come back is folded like the result of a lane of
+                // this wave (the lane "finishes" that part right here); a slot nobody claimed is taken back and searched here.
+                if (lane < GX_SLOTS && __hip_atomic_load(gstate + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1) {
+                    unsigned long long* sl = gx->slots + ((size_t)gx_block * GX_SLOTS + lane) * GX_GRANULES;
+                    const unsigned long long r3 = gx_load(sl + 8), cl = gx_load(sl + 4);
+                    int expect = 1;
+                    if (r3 != GX_EMPTY) {
+                        if (__hip_atomic_compare_exchange_strong(gstate + lane, &expect, 2, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                            // (the four result granules are written together: the others are a moment away at most; one at a time -- registers)
+                            auto wait_granule = [&](const unsigned long long* g) { unsigned long long v = gx_load(g); for (int sp = 0; v == GX_EMPTY && sp < (1 << 18); sp++) v = gx_load(g); if (v == GX_EMPTY && fault) atomicOr(fault, 1); return v; };
+                            owner = (int)(ga[lane].x & 0xFFFFu);
+                            wp = (int)(unsigned int)r3;
+                            { const unsigned long long r0 = wait_granule(sl + 5); wi = (int)(unsigned int)r0; wb = __uint_as_float((unsigned int)(r0 >> 32)); }
+                            { const unsigned long long r1 = wait_granule(sl + 6); l2 = (int)(unsigned int)r1; b2 = __uint_as_float((unsigned int)(r1 >> 32)); }
+                            { const unsigned long long r2 = wait_granule(sl + 7); b3 = __uint_as_float((unsigned int)r2); mlb = (unsigned int)(r2 >> 32); }
+                            st.alive = false; st.pending = 0;
+                            gmine = true; GX_COUNT(3, 1);
+                        }
+                    } else if (cl == 1ull) {
+                        if (__hip_atomic_compare_exchange_strong(gstate + lane, &expect, 2, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                            unsigned long long ce = 1ull;
+                            if (__hip_atomic_compare_exchange_strong(sl + 4, &ce, 3ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                                const uint2 ia = ga[lane], ib = gb[lane];
+                                owner = (int)(ia.x & 0xFFFFu);
+                                const uint2 c = lbq[5 * NT + owner], d = lbq[7 * NT + owner];
+                                qp.p2[0].x = __uint_as_float(c.y); qp.p2[0].y = qp.p2[0].x; qp.p2[1].x = __uint_as_float(d.x); qp.p2[1].y = qp.p2[1].x; qp.p2[2 % DIM].x = __uint_as_float(d.y); qp.p2[2 % DIM].y = qp.p2[2 % DIM].x;
+                                wb = __uint_as_float(ib.x); wi = (int)ib.y; wp = gp[lane];
+                                b2 = FLT_MAX; b3 = FLT_MAX; l2 = -1; mlb = FMAXB;
+                                thr = fminf(wb * ICP_PRUNE_SLACK, FLT_MAX);
+                                st.L = (int)(ia.x >> 16); st.idx = (int)ia.y; st.pending = 0; st.alive = true;
+                                gmine = true; GX_COUNT(2, 1);
+                            } else __hip_atomic_store(gstate + lane, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // a helper was faster: its result will come
+                        }
+                    }
+                    if (gmine) {
+                        if ((owner >> 6) == myw) __hip_atomic_fetch_sub(xc + 4 + myw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // back home
+                        gx_store(sl + 0, GX_EMPTY); gx_store(sl + 1, GX_EMPTY); gx_store(sl + 2, GX_EMPTY); gx_store(sl + 3, GX_EMPTY); gx_store(sl + 4, 0ull);      // the slot as it was found
+                        gx_store(sl + 5, GX_EMPTY); gx_store(sl + 6, GX_EMPTY); gx_store(sl + 7, GX_EMPTY); gx_store(sl + 8, GX_EMPTY);
+                    }
+                }
+            }
+            if (__any(mine) || __any(gmine)) {
                 if (polling) { polling = false; if (lane == 0) __hip_atomic_fetch_sub(xc + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
             } else {
                 if (MODE == 1) {
@@ -1016,7 +1100,41 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
                 }
             }
         }
-        if (XW && served && __builtin_amdgcn_readfirstlane(__hip_atomic_load(xc + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) > 0) {
+        const int idlew = (XW && served) ? __builtin_amdgcn_readfirstlane(__hip_atomic_load(xc + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) : 0;
+        if (ICP_GX && XW && GXON) {
+            if (trips == (gx->start_trips >> 1) && lane == 0) __hip_atomic_store(xc + 21, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // this block walks for long: its wave 0 will look for work elsewhere afterwards
+            if (served && idlew == 0 && trips >= gx->start_trips && (trips & 7) == 0) {
+                // GX: nobody in this block is idle and this wave has been at it for long: its lanes post their shallowest parked subtree in
+                // the block's outbox, for a block that is through with everything
+                const bool can = st.alive && st.pending != 0;
+                const unsigned long long dm = __ballot(can);
+                if (dm) {
+                    int base = 0;
+                    if (lane == 0) base = __hip_atomic_fetch_add(xc + 20, __popcll(dm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base < GX_SLOTS) {
+                        const int slot = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(dm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)dm, 0u));
+                        if (can && slot < GX_SLOTS) {
+                            const int low = sizeof(MaskT) == 8 ? __ffsll((long long)st.pending) - 1 : __ffs((int)st.pending) - 1;
+                            const int lv = low >> 2;
+                            st.pending &= ~((MaskT)1 << low);
+                            const unsigned int w0 = (unsigned int)owner | ((unsigned int)(lv + 1) << 16), w1 = (unsigned int)(((st.idx >> (2 * (st.L - lv))) << 2) | (low & 3));
+                            ga[slot] = make_uint2(w0, w1); gb[slot] = make_uint2(__float_as_uint(wb), (unsigned int)wi); gp[slot] = wp;
+                            __hip_atomic_fetch_add(xc + 4 + (owner >> 6), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_store(xc + 12 + (owner >> 6), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_store(gstate + slot, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            unsigned long long* sl = gx->slots + ((size_t)gx_block * GX_SLOTS + slot) * GX_GRANULES;
+                            gx_store(sl + 0, gx_pack(w0, w1)); gx_store(sl + 1, gx_pack(__float_as_uint(wb), (unsigned int)wi));
+                            gx_store(sl + 2, gx_pack((unsigned int)wp, __float_as_uint(qp.p2[0].x))); gx_store(sl + 3, gx_pack(__float_as_uint(qp.p2[1].x), __float_as_uint(qp.p2[2 % DIM].x)));
+                            gx_store(sl + 4, 1ull);
+                            GX_COUNT(0, 1);
+                        }
+                        if (lane == 0) atomicMax(gx->hdr + 2 * gx_block, (unsigned int)min(base + __popcll(dm), GX_SLOTS));
+                    }
+                }
+            }
+        }
+        if (XW && served && idlew > 0) {
             // another wave of the block waits for work and this wave's own lanes are all busy: lanes that still have parked subtrees put
             // their shallowest one on the board
             const bool can = st.alive && st.pending != 0;
@@ -1065,6 +1183,15 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
     if (XW && polling && lane == 0) __hip_atomic_fetch_sub(xc + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::"v"(touched));
     if (HELP) return;
+    if (PROXY) {                                                          // raw: what the owner folds like the result of one of its own lanes
+        const unsigned long long key = keys[tid], key2 = keys[NT + tid];
+        const uint2 b = R[2 * NT + lane];
+        best = __uint_as_float((unsigned int)(key >> 32)); bi = (int)(unsigned int)key; bpos = (int)b.y;
+        lb_others = key2 == ~0ull ? FLT_MAX : __uint_as_float((unsigned int)(key2 >> 32)); l2o = key2 == ~0ull ? -1 : (int)(unsigned int)key2;
+        lb3 = __uint_as_float(b.x);
+        keep3[0] = __uint_as_float(((const unsigned int*)(R + 6 * NT))[WAVE + lane]);
+        return;
+    }
     {
         const uint2 c = R[5 * NT + lane], d = R[7 * NT + lane], e = R[8 * NT + lane], f = R[9 * NT + lane];
         p[0] = __uint_as_float(c.y); p[1] = __uint_as_float(d.x); p[2] = __uint_as_float(d.y);
@@ -1095,11 +1222,62 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
 // XW, a wave that has nothing of its own left to do (its pairs are weighed, only the block's sums remain): help the block's other waves
 // until every wave that searched is complete.  The wave's rows 3.. are not touched (the caller parks its pair there).
 template <int DIM, int NT, class MaskT>
-__device__ __forceinline__ void xw_help(const BvhViewT<DIM>& bv, uint2* __restrict__ lbq, int tid, int* fault) {
+__device__ __forceinline__ void xw_help(const BvhViewT<DIM>& bv, uint2* __restrict__ lbq, int tid, int* fault, const GxParams* gx, int gx_block) {
     float p[DIM], k3[3] = {0.f, 0.f, 0.f}, best = FLT_MAX, lbo = 0.f, lb3 = 0.f; int bi = -1, bpos = -1, l2 = -1;
 #pragma unroll
     for (int q = 0; q < DIM; q++) p[q] = 0.f;
-    knn_walk_shared<DIM, NT, MaskT, 2>(bv, p, k3, false, best, bi, bpos, lbo, lb3, l2, lbq, tid, fault);
+    knn_walk_shared<DIM, NT, MaskT, 2>(bv, p, k3, false, best, bi, bpos, lbo, lb3, l2, lbq, tid, fault, gx, gx_block);
+}
+
+// GX: wave 0 of a block that is through with everything looks into the outboxes of other blocks (64 of them per round, one per lane),
+// claims a posted subtree, searches it with the whole wave and writes the result back; it leaves after gx.empty_rounds rounds in a row
+// without a claim.
+constexpr int GX_MAX_ROUNDS = 1 << 14;
+template <int DIM, int NT, class MaskT>
+__device__ __forceinline__ void gx_help(const BvhViewT<DIM>& bv, const GxParams& gx, int my_block, int nblocks, uint2* __restrict__ lbq, int tid) {
+    const int lane = tid & 63;
+    int empty = 0;
+    if (lane == 0) GX_COUNT(4, 1);
+    for (int r = 0; r < GX_MAX_ROUNDS && empty < gx.empty_rounds; r++) {
+        if (lane == 0) GX_COUNT(5, 1);
+        const unsigned int v = ((unsigned int)my_block * 97u + (unsigned int)r * 64u + (unsigned int)lane + 1u) % (unsigned int)nblocks;
+        bool got = false;
+        unsigned long long* sl = nullptr;
+        if ((int)v != my_block) {
+            const unsigned long long h = gx_load((const unsigned long long*)gx.hdr + v);      // (posted, lowest slot that may be unclaimed)
+            const unsigned int posted = (unsigned int)h, hint = (unsigned int)(h >> 32);
+            if (hint < posted && hint < (unsigned int)GX_SLOTS) {
+                sl = gx.slots + ((size_t)v * GX_SLOTS + hint) * GX_GRANULES;
+                const unsigned long long cl = gx_load(sl + 4);
+                unsigned long long ce = 1ull;
+                if (cl == 1ull && __hip_atomic_compare_exchange_strong(sl + 4, &ce, 2ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) got = true;
+                if (got || cl >= 2ull) atomicMax(gx.hdr + 2 * v + 1, hint + 1u);      // (claimed by somebody: the next prober starts one further)
+            }
+        }
+        if (!__any(got)) { empty++; __builtin_amdgcn_s_sleep(16); continue; }
+        empty = 0;
+        if (got) GX_COUNT(1, 1);
+        if (lane == 0) GX_COUNT(6, 1);
+        float p[DIM], k3[3] = {0.f, 0.f, 0.f}, best = FLT_MAX, lbo = 0.f, lb3 = 0.f; int bi = -1, bpos = -1, l2 = -1, L = 0, idx = 0;
+#pragma unroll
+        for (int q = 0; q < DIM; q++) p[q] = 0.f;
+        if (got) {
+            unsigned long long g0 = GX_EMPTY, g1 = GX_EMPTY, g2 = GX_EMPTY, g3 = GX_EMPTY;
+            for (int sp = 0; sp < (1 << 18); sp++) {                      // (item and claim word were written together)
+                g0 = gx_load(sl + 0); g1 = gx_load(sl + 1); g2 = gx_load(sl + 2); g3 = gx_load(sl + 3);
+                if (g0 != GX_EMPTY && g1 != GX_EMPTY && g2 != GX_EMPTY && g3 != GX_EMPTY) break;
+            }
+            L = (int)(((unsigned int)g0 >> 16) & 0xFFu); idx = (int)(unsigned int)(g0 >> 32);
+            best = __uint_as_float((unsigned int)g1); bi = (int)(unsigned int)(g1 >> 32);
+            bpos = (int)(unsigned int)g2; p[0] = __uint_as_float((unsigned int)(g2 >> 32)); p[1] = __uint_as_float((unsigned int)g3); p[2 % DIM] = __uint_as_float((unsigned int)(g3 >> 32));
+            if (g0 == GX_EMPTY || g1 == GX_EMPTY || g2 == GX_EMPTY || g3 == GX_EMPTY || L < 1 || L > bv.Lq || bpos < 0) got = false;      // (never seen; an unusable item stays claimed and the owner's bounded wait reports it)
+        }
+        knn_walk_shared<DIM, NT, MaskT, 3>(bv, p, k3, got, best, bi, bpos, lbo, lb3, l2, lbq, tid, nullptr, nullptr, 0, L, idx);
+        if (got) {
+            gx_store(sl + 5, gx_pack((unsigned int)bi, __float_as_uint(best))); gx_store(sl + 6, gx_pack((unsigned int)l2, __float_as_uint(lbo)));
+            gx_store(sl + 7, gx_pack(__float_as_uint(lb3), __float_as_uint(k3[0]))); gx_store(sl + 8, gx_pack((unsigned int)bpos, 1u));
+        }
+    }
 }
 
 __device__ __forceinline__ float wave_min_f32(float v) {

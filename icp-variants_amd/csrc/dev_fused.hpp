@@ -33,6 +33,9 @@ struct P2pGen {                                           // values 0..21 = sum 
 // query, a stable 8-class rank in the epilogue): iterations 1-9 0.084 vs 0.079 ms -- the prediction is not worth the extra dependent
 // load in front of everything and the gathers.  What did pay was making k_reduce_solve itself cheaper (one load
 // round, fence-free hand-over): see dev_solve.hpp.
+#ifndef ICP_FUSED_WAVES
+#define ICP_FUSED_WAVES 6        // waves per SIMD the 3-D fused matchers are compiled for (80 registers)
+#endif
 #ifndef ICP_WAVE_STRIDE
 #define ICP_WAVE_STRIDE ((ICP_XW && ICP_BVH_THREADS > 64) ? 128 : 0)      // 1: the waves of a block come from BVH_THREADS / 64 places of the query order (hard and easy regions meet in one block: knn_walk_shared, XW)
 #endif
@@ -108,7 +111,7 @@ struct PairOut { bool valid; float s0, s1, s2, d0, d1, d2, n0, n1, n2, wt; };
 // cannot be given that way (no record fetched: the neighbour is past the distance threshold) leaves `searched` set instead.
 template <int DIM, bool WIDE, bool XW = false>
 __device__ __forceinline__ void fused_search_post(const KnnParams& kp, const BvhViewT<DIM>& bv, const PostParams& pp, int k, bool seeded, bool inc, const float* Pm, const float* Nm,
-                                                  QueryIn<DIM>& in, uint2* __restrict__ bvh_lbq, int tid, int wave_slot, PairOut& o, bool& searched, bool* renewed = nullptr) {
+                                                  QueryIn<DIM>& in, uint2* __restrict__ bvh_lbq, int tid, int wave_slot, PairOut& o, bool& searched, bool* renewed = nullptr, int gx_block = 0) {
     const int lane = tid & 63; (void)lane; (void)wave_slot; (void)seeded;
     o.valid = false; o.s0 = 0.f; o.s1 = 0.f; o.s2 = 0.f; o.d0 = 0.f; o.d1 = 0.f; o.d2 = 0.f; o.n0 = 0.f; o.n1 = 0.f; o.n2 = 0.f; o.wt = 0.f;
     float p[DIM];
@@ -192,7 +195,7 @@ __device__ __forceinline__ void fused_search_post(const KnnParams& kp, const Bvh
     if (__any(need_walk)) {
         walked = true;
         float rn[3] = {rn0, rn1, rn2};
-        knn_walk_shared<DIM, BVH_THREADS, typename std::conditional<WIDE, unsigned long long, unsigned int>::type, XW ? 1 : 0>(bv, p, rn, need_walk, best, bi, bpos, lb_others, lb3, l2, bvh_lbq, tid, kp.fault);
+        knn_walk_shared<DIM, BVH_THREADS, typename std::conditional<WIDE, unsigned long long, unsigned int>::type, XW ? 1 : 0>(bv, p, rn, need_walk, best, bi, bpos, lb_others, lb3, l2, bvh_lbq, tid, kp.fault, &kp.gx, gx_block);
         rn0 = rn[0]; rn1 = rn[1]; rn2 = rn[2];
         q0 = -2;                                          // the neighbour's record is read again below: it need not stay in registers while this lane helps
         // (the persistent loop: a wave that walked reloads its queries' data in the next iteration -- said here in a way the register
@@ -203,6 +206,7 @@ __device__ __forceinline__ void fused_search_post(const KnnParams& kp, const Bvh
     if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lb3, l2, bvh_lbq, tid, (ICP_DEBUG_STEPS && kp.dbg_steps) ? kp.dbg_steps + k : nullptr);
 #endif
     ICP_STAMP(2);
+    asm volatile("" : "+v"(k));                           // (the addresses of this query's state and records are formed HERE, not held in registers across the walk)
     if (k >= 0) {
         // A verified query keeps its stored anchor (position of the last full search) and bound: the triangle test stays valid
         // against the OLD anchor -- and is tighter than re-anchoring, (L - d1) - d2 <= L - |d1 + d2| -- and its neighbour is
@@ -314,7 +318,7 @@ __device__ __forceinline__ void fused_matcher_body(const KnnParams& kp, const Bv
     }
     if constexpr (MERGED) { if (!ring_wait_pose(loop_slot((PoseState*)kp.ps, 0, (int)((blockIdx.x * 2u + (unsigned int)w) % (unsigned int)POSE_REPLICAS)), lane, rp.run_fault, Pm, Nm)) return; }
     PairOut o; bool searched;
-    fused_search_post<DIM, WIDE, XW>(kp, bv, pp, k, seeded, inc, Pm, Nm, in, bvh_lbq, tid, wave_slot, o, searched);
+    fused_search_post<DIM, WIDE, XW>(kp, bv, pp, k, seeded, inc, Pm, Nm, in, bvh_lbq, tid, wave_slot, o, searched, nullptr, lb);
     if constexpr (XW) {
         // this wave holds its pairs; before the block's sums, it helps the waves of the block that still search (the pair waits in the
         // wave's own LDS rows, which nobody reads once its queries are complete)
@@ -323,7 +327,7 @@ __device__ __forceinline__ void fused_matcher_body(const KnnParams& kp, const Bv
             bvh_lbq[3 * NT + tid] = make_uint2(__float_as_uint(o.s0), __float_as_uint(o.s1)); bvh_lbq[4 * NT + tid] = make_uint2(__float_as_uint(o.s2), __float_as_uint(o.d0));
             bvh_lbq[5 * NT + tid] = make_uint2(__float_as_uint(o.d1), __float_as_uint(o.d2)); bvh_lbq[7 * NT + tid] = make_uint2(__float_as_uint(o.n0), __float_as_uint(o.n1));
             bvh_lbq[8 * NT + tid] = make_uint2(__float_as_uint(o.n2), __float_as_uint(o.wt)); bvh_lbq[9 * NT + tid] = make_uint2(o.valid ? 1u : 0u, 0u);
-            xw_help<DIM, NT, typename std::conditional<WIDE, unsigned long long, unsigned int>::type>(bv, bvh_lbq, tid, kp.fault);
+            xw_help<DIM, NT, typename std::conditional<WIDE, unsigned long long, unsigned int>::type>(bv, bvh_lbq, tid, kp.fault, &kp.gx, lb);
             const uint2 a = bvh_lbq[3 * NT + tid], b = bvh_lbq[4 * NT + tid], c = bvh_lbq[5 * NT + tid], d = bvh_lbq[7 * NT + tid], e = bvh_lbq[8 * NT + tid], f = bvh_lbq[9 * NT + tid];
             o.s0 = __uint_as_float(a.x); o.s1 = __uint_as_float(a.y); o.s2 = __uint_as_float(b.x); o.d0 = __uint_as_float(b.y); o.d1 = __uint_as_float(c.x); o.d2 = __uint_as_float(c.y);
             o.n0 = __uint_as_float(d.x); o.n1 = __uint_as_float(d.y); o.n2 = __uint_as_float(e.x); o.wt = __uint_as_float(e.y); o.valid = f.x != 0u;
@@ -331,16 +335,26 @@ __device__ __forceinline__ void fused_matcher_body(const KnnParams& kp, const Bv
     }
     double* partials = pp.partials;
     fused_block_epilogue(kp, pp, o, bvh_lbq, tid, wave_slot, [=](int a, double v) { partials[(size_t)a * mgrid + lb] = v; });
+    if constexpr (XW && ICP_GX) {
+        if (kp.gx.slots) {
+            // GX: the block's partial is on its way.  Its outbox is as it was found (every posted slot was folded or taken back before the
+            // block's sums) -- the header still says otherwise; and if this block walked for long, so do others: wave 0 goes and helps.
+            const int* xc = (const int*)(bvh_lbq + ICP_SHARE_ROWS * BVH_THREADS);
+            const int posted = xc[20], walked_long = xc[21];
+            if (tid == 0 && posted > 0) gx_store((unsigned long long*)kp.gx.hdr + lb, 0ull);
+            if (tid < WAVE && walked_long) gx_help<DIM, BVH_THREADS, typename std::conditional<WIDE, unsigned long long, unsigned int>::type>(bv, kp.gx, lb, mgrid, bvh_lbq, tid);
+        }
+    }
 }
 template <int DIM, bool WIDE>
-__global__ __launch_bounds__(BVH_THREADS, DIM == 3 ? 6 : 4) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {
+__global__ __launch_bounds__(BVH_THREADS, DIM == 3 ? ICP_FUSED_WAVES : 4) void k_knn_bvh_post(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp) {
     const RingParams none{};
     fused_matcher_body<DIM, WIDE, false>(kp, bv, qorder, pp, none);
 }
 // The merged loop's launch: blocks [0, rp.n_red) = reducer of the previous iteration, the rest = this iteration's matcher (kp.ps = the
 // pose slot they wait for).
 template <int DIM, bool WIDE>
-__global__ __launch_bounds__(BVH_THREADS, DIM == 3 ? 6 : 4) void k_knn_bvh_post_ring(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp, const RingParams rp) {
+__global__ __launch_bounds__(BVH_THREADS, DIM == 3 ? ICP_FUSED_WAVES : 4) void k_knn_bvh_post_ring(const KnnParams kp, const BvhViewT<DIM> bv, const int* __restrict__ qorder, const PostParams pp, const RingParams rp) {
     static_assert(BVH_THREADS >= RING_THREADS, "the reducer blocks are the first RING_THREADS threads of a matcher-sized block");
     fused_matcher_body<DIM, WIDE, true>(kp, bv, qorder, pp, rp);
 }

@@ -10,6 +10,12 @@
 // Block = 4 waves sharing the same 64 queries; wave w scans quarter w of the block's target
 // segment; blockIdx.y splits the target range further for small query counts (merged with a
 // packed (d2 bits, index) 64-bit atomicMin = lexicographic first-minimum).
+struct GxParams {               // hand-over of parked subtrees between the blocks of a fused BVH matcher launch (dev_bvh.hpp, GX)
+    unsigned long long* slots;   // [blocks][GX_SLOTS][GX_GRANULES]; nullptr: off
+    unsigned int* hdr;           // [blocks][2]: slots posted so far, lowest slot that may still be unclaimed
+    int start_trips;             // a wave posts once its walk has lasted this many passes of the hand-over loop
+    int empty_rounds;            // a helper leaves after this many probe rounds without a claim
+};
 struct KnnParams {
     const float* sx; const float* sy; const float* sz;       // source planes (untransformed unless pretransformed)
     const float* scr; const float* scg; const float* scb;    // source colour features (DIM=6)
@@ -30,6 +36,7 @@ struct KnnParams {
     float2* qstate2;                                         // [n] (lower bound, at the same anchor, on every target outside the neighbour's leaf and the runner-up's leaf; that second leaf as int bits, -1: none)
     int* dbg_steps;                                          // development builds (ICP_DEBUG_STEPS): [n] nodes | leaves << 16 visited by the walk of query k; nullptr otherwise
     int* fault;                                              // fused BVH matcher: raised when a bounded wait of the cross-wave hand-over runs out (cannot happen; knn_walk_shared)
+    GxParams gx;                                             // fused BVH matcher: outboxes of the hand-over between blocks (dev_bvh.hpp, GX); slots == nullptr: off
     int dbg_waves;                                           // development builds (ICP_DEBUG_TIMES): waves of the launch = where the per-query records start in dbg_steps
 };
 

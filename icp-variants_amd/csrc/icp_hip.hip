@@ -90,6 +90,8 @@ struct icp_ctx {
     int loop_capacity[4] = {0, 0, 0, 0}; // resident blocks of k_icp_loop<3/6, false/true> on this device (0: not asked yet)
     int merged_runs = 0, merged_fallbacks = 0;   // runs that took the merged loop / that had to be repeated with the separate launches (icp_debug_counters)
     bool ext_events = true;              // merged form: stage times from hipExtLaunchKernel's start / stop events (ICP_HIP_EXT_EVENTS=0: hipEventRecord brackets)
+    bool gx_on = ICP_GX != 0; int gx_start = 16, gx_empty = 3;   // hand-over between the blocks of the fused matcher (dev_bvh.hpp, GX): ICP_HIP_GX=0 disables; ICP_HIP_GX_START / ICP_HIP_GX_EMPTY
+    DevBuf gx_slots, gx_hdr; int gx_blocks = 0; bool gx_dirty = false;      // the outboxes (armed once: every launch leaves them as it found them; gx_dirty: a run was cut short)
     bool keep_fused_records = false;     // icp_match_seeded: the fused matcher also writes its Match records and distances (the loop itself never reads them)
     icp_params prm;
     Cloud tgt, src, qry;                 // qry: scratch cloud of icp_query_matches
@@ -446,6 +448,27 @@ PostParams make_post_params(icp_ctx* c, const Cloud& src, const int* sel, int n)
     return pp;
 }
 
+// The outboxes of the hand-over between blocks (GX): armed for `blocks` blocks -- granules all-ones, claim words and headers zero.
+__global__ void k_gx_init(unsigned long long* slots, size_t n_granules, unsigned int* hdr, size_t n_hdr) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_granules) slots[i] = (i % GX_GRANULES == 4) ? 0ull : GX_EMPTY;
+    if (i < n_hdr) hdr[i] = 0u;
+}
+static int ensure_gx(icp_ctx* c, int blocks) {
+    if (!c->gx_on || c->shared_gpu) return ICP_OK;
+    int rc;
+    if (blocks > c->gx_blocks || c->gx_dirty) {
+        const int nbk = blocks > c->gx_blocks ? blocks : c->gx_blocks;
+        const size_t ng = (size_t)nbk * GX_SLOTS * GX_GRANULES;
+        if ((rc = ensure(c, c->gx_slots, ng * 8))) return rc;
+        if ((rc = ensure(c, c->gx_hdr, (size_t)nbk * 8))) return rc;
+        hipLaunchKernelGGL(k_gx_init, dim3((unsigned int)((ng + 255) / 256)), dim3(256), 0, c->stream, c->gx_slots.as<unsigned long long>(), ng, c->gx_hdr.as<unsigned int>(), (size_t)nbk * 2);
+        HIPCK(c, hipGetLastError());
+        c->gx_blocks = nbk; c->gx_dirty = false;
+    }
+    return ICP_OK;
+}
+
 // fuse != nullptr: run the post stage (weight / reject / accumulate) as the epilogue of the search; *fused_blocks receives the
 // number of block partials written.
 template <int DIM>
@@ -460,6 +483,10 @@ int launch_bvh_query(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp, const KnnPara
         if ((rc = ensure(c, c->partials, (size_t)(nb > POST_BLOCKS ? nb : POST_BLOCKS) * NSUM * 8))) return rc;
         PostParams pp = make_post_params(c, *fuse, kp.sel, n);
         KnnParams kf = kp; kf.out = nullptr;
+        if (DIM == 3 && c->gx_on && !c->shared_gpu && !(ml && ml->loop)) {
+            if ((rc = ensure_gx(c, nb))) return rc;
+            kf.gx = GxParams{c->gx_slots.as<unsigned long long>(), c->gx_hdr.as<unsigned int>(), c->gx_start, c->gx_empty};
+        }
         if (!c->keep_fused_records) { pp.matches = nullptr; kf.d2_out = nullptr; }     // the loop never reads the records of a fused iteration, nor the distances
         const size_t red_bytes = (size_t)(BVH_THREADS / WAVE) * 33 * 8;           // the reduction reuses the (dead) traversal stacks
         static const size_t lds_pad = getenv("ICP_HIP_LDS_PAD") ? (size_t)atoi(getenv("ICP_HIP_LDS_PAD")) : 0;      // development: fewer resident blocks per CU
@@ -526,7 +553,7 @@ int launch_match(icp_ctx* c, const QuerySet& q, int* fused_blocks = nullptr, con
     kp.tx = c->tgt.x.as<float>(); kp.ty = c->tgt.y.as<float>(); kp.tz = c->tgt.z.as<float>();
     kp.tcr = c->tgt.cr.as<float>(); kp.tcg = c->tgt.cg.as<float>(); kp.tcb = c->tgt.cb.as<float>();
     kp.mpad = c->tgt.npad; kp.ps = c->ps.as<PoseState>(); kp.pretransformed = q.pretransformed; kp.max_dist = p.max_distance;
-    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0; kp.qstate = nullptr; kp.qstate2 = nullptr; kp.incremental = 0; kp.dbg_steps = nullptr; kp.dbg_waves = 0; kp.fault = &c->ps.as<PoseState>()->fault;
+    kp.out = c->matches.as<icp_match_t>(); kp.d2_out = c->d2.as<float>(); kp.best64 = nullptr; kp.nn_raw = nullptr; kp.use_prev = 0; kp.qstate = nullptr; kp.qstate2 = nullptr; kp.incremental = 0; kp.dbg_steps = nullptr; kp.dbg_waves = 0; kp.fault = &c->ps.as<PoseState>()->fault; kp.gx = GxParams{nullptr, nullptr, 0, 0};
     if (p.knn_backend == ICP_KNN_LBVH) {
         kp.nseg = 1;
         // neighbour positions and the incremental search's state in ONE allocation, sections a fixed number of elements apart
@@ -754,6 +781,9 @@ int icp_ctx_create_on_stream(int device, void* hip_stream, icp_ctx** out) {
     { const char* e = getenv("ICP_HIP_SPIN_REDUCE"); if (e) c->spin_reduce = e[0] == '1'; }
     { const char* e = getenv("ICP_HIP_TIER2"); if (e && e[0] == '0') c->tier2 = false; }
     { const char* e = getenv("ICP_HIP_MERGE"); if (e && e[0] == '0') c->merge_loop = false; }
+    { const char* e = getenv("ICP_HIP_GX"); if (e && e[0] == '0') c->gx_on = false; }
+    { const char* e = getenv("ICP_HIP_GX_START"); if (e && atoi(e) > 1) c->gx_start = atoi(e); }
+    { const char* e = getenv("ICP_HIP_GX_EMPTY"); if (e && atoi(e) > 0) c->gx_empty = atoi(e); }
     { const char* e = getenv("ICP_HIP_PERSIST"); if (e) c->persist_loop = e[0] == '1'; }
     { const char* e = getenv("ICP_HIP_EXT_EVENTS"); if (e && e[0] == '0') c->ext_events = false; }
     { const char* e = getenv("ICP_HIP_LOOP_FROM"); if (e) c->loop_from = atoi(e); }
@@ -786,7 +816,7 @@ int icp_ctx_destroy(icp_ctx* c) {
     for (Bvh* b : {&c->bvh6, &c->nrm_bvh}) { release(b->keys); release(b->keys2); release(b->vals); release(b->vals2); release(b->temp); release(b->leaves); release(b->nodes); release(b->lvl); release(b->wbox); }
     release(c->bvh.keys); release(c->bvh.keys2); release(c->bvh.vals); release(c->bvh.vals2); release(c->bvh.temp); release(c->bvh.leaves); release(c->okeys); release(c->okeys2); release(c->ovals); release(c->otemp); release(c->bvh.nodes); release(c->bvh.lvl); release(c->bvh.wbox);
     for (auto& kv : c->levels) release(kv.second);
-    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->qstate2); release(c->qpack); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->partials2); release(c->ring); release(c->pring); release(c->totals); release(c->dbg_steps); release(c->sums);
+    release(c->ps); release(c->matches); release(c->d2); release(c->best64); release(c->nn_raw); release(c->qstate); release(c->qstate2); release(c->qpack); release(c->sel_lists); release(c->sel_counts); release(c->sel_blocks); release(c->partials); release(c->partials2); release(c->ring); release(c->pring); release(c->totals); release(c->dbg_steps); release(c->sums); release(c->gx_slots); release(c->gx_hdr);
     release(c->stats); release(c->staging); release(c->rmse_partials); release(c->rmse_out); release(c->fontana_partials);
     for (DevBuf* d : {&c->src_flag, &c->src_box, &c->tgt_flag, &c->tgt_finite, &c->nrm_finite, &c->sel_temp, &c->d_count}) release(*d);
     if (c->pin_up) (void)hipHostFree(c->pin_up);
@@ -1180,6 +1210,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
         if ((rc = ensure(c, c->ring, slot_bytes + tot_bytes))) return rc;
         if ((rc = ensure(c, c->partials, (size_t)nbmax * NSUM * 8))) return rc;
         if ((rc = ensure(c, c->partials2, (size_t)nbmax * NSUM * 8))) return rc;
+        if (!p.color_icp && (rc = ensure_gx(c, nbmax))) return rc;
         slots = c->ring.as<PoseState>(); trows = (unsigned long long*)(c->ring.as<char>() + slot_bytes); run_fault = (int*)(c->stats.as<char>() + stats_pad + 128);
         const int n_init = (iters + 1) * POSE_REPLICAS * 16 + iters * NSUM + 16;
         hipLaunchKernelGGL(k_run_init, dim3((n_init + 255) / 256), dim3(256), 0, c->stream, c->ps.as<PoseState>(), slots, iters + 1, trows, iters * NSUM, run_fault, 16);      // (both rings are reset: nothing survives an aborted run)
@@ -1293,7 +1324,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
         if (hp->fault || rf) {
             // a pivot of the 6 x 6 system failed the rank test (the eigen fallback lives in k_reduce_solve only), or a bounded wait ran out:
             // the same run again, from the incoming pose, with the separate launches
-            c->merged_fallbacks++;
+            c->merged_fallbacks++; c->gx_dirty = true;     // (a run cut short may have left claimed slots in the outboxes)
             if (c->trace) fprintf(stderr, "[icp_hip] %s gave up: slot fault %d, abort word %d -> the run again with separate launches\n", persist ? "k_icp_loop" : "merged loop", hp->fault, rf);
             guard.ok = true;                                 // synchronised
             memcpy(pose_inout, pose_in, 64);
@@ -1307,7 +1338,7 @@ static int run_loop(icp_ctx* c, float pose_inout[16], icp_iter_stats* stats, int
     }
     memcpy(hs.data(), (char*)c->pinned + pin_stats, (size_t)iters * sizeof(icp_iter_stats));
     memcpy(pose_inout, ((const PoseState*)((char*)c->pinned + pin_pose))->pose, 64);
-    if (((const PoseState*)((char*)c->pinned + pin_pose))->fault) { c->err = "reduction hand-over timed out on the device (k_reduce_solve)"; return ICP_ERR_HIP; }
+    if (((const PoseState*)((char*)c->pinned + pin_pose))->fault) { c->gx_dirty = true; c->err = "reduction hand-over timed out on the device (k_reduce_solve)"; return ICP_ERR_HIP; }
     int status = ICP_OK;
     for (int i = 0; i < iters; i++) {
         if (ns[i] <= 0) { hs[i].n_src = 0; hs[i].n_valid = 0; hs[i].status = ICP_ERR_NO_CORRESPONDENCES; memcpy(hs[i].pose, i ? hs[i - 1].pose : pose_in, 64); hs[i].rmse = -1.f; hs[i].benchmark_error = -1.f; }
@@ -1553,6 +1584,20 @@ int icp_debug_ring_times(icp_ctx* c, int32_t* out, int32_t n) {     // developme
     return ICP_OK;
 #else
     (void)c; (void)out; (void)n;
+    return ICP_ERR_INVALID_ARG;
+#endif
+}
+int icp_debug_gx_counters(icp_ctx* c, uint32_t* out16, int32_t reset) {     // development builds (ICP_DEBUG_TIMES): events of the hand-over between blocks since the last reset
+#if ICP_DEBUG_TIMES
+    if (!c || !out16) return ICP_ERR_INVALID_ARG;
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    HIPCK(c, hipMemcpyFromSymbol(out16, HIP_SYMBOL(icpdev::g_gx_dbg), 64));
+    if (reset) { uint32_t z[16] = {0}; HIPCK(c, hipMemcpyToSymbol(HIP_SYMBOL(icpdev::g_gx_dbg), z, 64)); }
+    return ICP_OK;
+#else
+    (void)c; (void)out16; (void)reset;
     return ICP_ERR_INVALID_ARG;
 #endif
 }
