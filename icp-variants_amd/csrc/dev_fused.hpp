@@ -93,7 +93,7 @@ __device__ __forceinline__ void fused_front_loads(const KnnParams& kp, const Pos
 // Which 64 queries of the (Morton-sorted) order does wave w of logical block lb take?  ICP_WAVE_STRIDE 0: the block's waves are
 // neighbours; 1: they come from NW places of the order, a grid's worth of waves apart (hard and easy regions meet in one block);
 // S > 1: from NW places S waves apart (groups of S blocks share a stretch of NW * S waves; a last, partial group keeps neighbours).
-__device__ __forceinline__ int fused_wave_slot(int lb, int w, int mgrid) {
+__host__ __device__ __forceinline__ int fused_wave_slot(int lb, int w, int mgrid) {
     constexpr int NW = BVH_THREADS / WAVE, S = ICP_WAVE_STRIDE;
     if (S == 0 || NW == 1) return lb * NW + w;
     if (S == 1) return w * mgrid + lb;

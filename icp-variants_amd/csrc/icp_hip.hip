@@ -1601,6 +1601,31 @@ int icp_debug_gx_counters(icp_ctx* c, uint32_t* out16, int32_t reset) {     // d
     return ICP_ERR_INVALID_ARG;
 #endif
 }
+//   icp_debug_wave_slot       : host evaluation of the fused matcher's block -> wave mapping (fused_wave_slot): which stretch of 64 queries
+//                               wave w of logical block lb takes in a grid of mgrid blocks; *waves_per_block receives BVH_THREADS / 64.  No GPU needed.
+//   icp_debug_pos_of_mismatches: entries of the resident target's position-by-index map that do not point back at their record (must be 0).
+int icp_debug_wave_slot(int32_t lb, int32_t w, int32_t mgrid, int32_t* waves_per_block) {
+    if (waves_per_block) *waves_per_block = BVH_THREADS / WAVE;
+    if (lb < 0 || lb >= mgrid || w < 0 || w >= BVH_THREADS / WAVE) return -1;
+    return icpdev::fused_wave_slot(lb, w, mgrid);
+}
+__global__ void k_debug_pos_of(const icpdev::TgtRec* recs, const int* pos_of, int n_slots, int* bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_slots && recs[i].idx >= 0 && pos_of[recs[i].idx] != i) atomicAdd(bad, 1);
+}
+int icp_debug_pos_of_mismatches(icp_ctx* c, int32_t* n_bad, int32_t* n_checked) {
+    if (!c || !n_bad || !c->bvh.valid) return ICP_ERR_INVALID_ARG;
+    int rc;
+    if ((rc = set_device(c))) return rc;
+    const int n_slots = (c->bvh.n_leaves > 0 ? c->bvh.n_leaves : 1) * BVH_LEAF;
+    if ((rc = ensure(c, c->d_count, 4))) return rc;
+    HIPCK(c, hipMemsetAsync(c->d_count.p, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_debug_pos_of, dim3((n_slots + 255) / 256), dim3(256), 0, c->stream, c->bvh.recs.as<icpdev::TgtRec>(), c->bvh.pos_of.as<int>(), n_slots, c->d_count.as<int>());
+    HIPCK(c, hipMemcpyAsync(n_bad, c->d_count.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (n_checked) *n_checked = c->bvh.n_valid;
+    return ICP_OK;
+}
 int icp_debug_counters(icp_ctx* c, int32_t* merged_runs, int32_t* merged_fallbacks) {
     if (!c) return ICP_ERR_INVALID_ARG;
     if (merged_runs) *merged_runs = c->merged_runs + c->loop_runs;

@@ -98,3 +98,24 @@ def test_missing_rccl_is_an_error_code_not_a_crash():
     assert int(rc) == 10                                    # ICP_ERR_COMM
     assert int(rc2) in (9, 10)                              # no HIP device on a CPU box (ICP_ERR_NO_DEVICE), ICP_ERR_COMM on a GPU box
     assert "ICP_HIP_RCCL_LIB" in msg and "/nonexistent/librccl.so.1" in msg
+
+
+def test_fused_matcher_wave_mapping_is_a_permutation():
+    """fused_wave_slot (dev_fused.hpp): the waves of a block come from several places of the query order (the cross-wave hand-over pairs
+    hard and easy regions).  Whatever the stride and the grid, every stretch of 64 queries must belong to exactly one (block, wave) --
+    a hole would silently drop queries, an overlap would count them twice.  Evaluated on the host through a debug hook: no GPU."""
+    from icp_amd import binding
+    lib = binding.load_library()
+    lib.icp_debug_wave_slot.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]
+    lib.icp_debug_wave_slot.restype = ctypes.c_int32
+    nw = ctypes.c_int32(0)
+    assert lib.icp_debug_wave_slot(0, 0, 1, ctypes.byref(nw)) == 0 and nw.value >= 1
+    for mgrid in (1, 2, 3, 7, 127, 128, 129, 255, 256, 257, 1447, 1448, 2895, 4099):
+        seen = np.zeros(mgrid * nw.value, np.int32)
+        for lb in range(mgrid):
+            for w in range(nw.value):
+                s = lib.icp_debug_wave_slot(lb, w, mgrid, None)
+                assert 0 <= s < mgrid * nw.value, (mgrid, lb, w, s)
+                seen[s] += 1
+        assert (seen == 1).all(), mgrid
+    assert lib.icp_debug_wave_slot(5, 0, 5, None) == -1 and lib.icp_debug_wave_slot(0, nw.value, 5, None) == -1

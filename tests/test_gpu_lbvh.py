@@ -204,3 +204,20 @@ def test_stage_timing_modes_do_not_change_the_result(gpu_ctx_factory, bunny):
     assert t0["sampled_iterations"] == 0 and t0["match_ms"] == 0 and t0["total_ms"] > 0
     assert t4["sampled_iterations"] == 3 and t4["match_ms"] > 0 and t4["total_ms"] > 0
     assert t4["match_ms"] + t4["solve_ms"] < 3 * t4["total_ms"]          # scaled sums stay in the right ballpark
+
+
+def test_position_by_index_map_points_back_at_the_records(gpu_ctx_factory, bunny):
+    """BvhViewT::pos_of (what a fold of the cross-wave hand-over falls back on when the position written beside the key lost a race):
+    for every record of the tree, pos_of[record.idx] is that record's position -- also with duplicate and non-finite targets."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    tp = np.concatenate([bunny["tgt_pts"], bunny["tgt_pts"][:500]]).astype(np.float32)          # exact duplicates
+    tp[rng.choice(len(tp), 40, replace=False)] = np.nan                                          # and points the index build drops
+    tn = np.concatenate([bunny["tgt_nrm"], bunny["tgt_nrm"][:500]]).astype(np.float32)
+    c = gpu_ctx_factory()
+    c.params.knn_backend = 1; c.params.metric = 1; c.params.max_distance = 0.0003; c.push_params()
+    c.set_target(tp, tn); c.set_source(bunny["src_pts"], bunny["src_nrm"])
+    c.match(np.eye(4))                                                                           # (builds the index)
+    bad, n = C.c_int32(-1), C.c_int32(0)
+    assert c.lib.icp_debug_pos_of_mismatches(c.h, C.byref(bad), C.byref(n)) == 0
+    assert bad.value == 0 and n.value == int(np.isfinite(tp).all(1).sum())
