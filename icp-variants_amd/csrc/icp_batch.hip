@@ -11,6 +11,8 @@
 // Only the public C ABI of icp_hip.h is used here (a context is driven exactly as a C++14 host would drive it).
 // =====================================================================================
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -50,17 +52,26 @@ int icp_batch_run(icp_ctx* const* ctxs, int32_t n_ctx, const icp_pair* pairs, in
     bool chain = n_pairs > 1;
     for (int32_t p = 1; p < n_pairs && chain; p++) chain = target_is_previous_source(pairs[p - 1], pairs[p]);
     std::atomic<int32_t> next(0);
+    // ICP_HIP_BATCH_TIMES=1: where the host threads' time goes (wall time inside the three calls of a pair, summed over the pairs) -> stderr
+    const bool times = getenv("ICP_HIP_BATCH_TIMES") != nullptr;
+    std::atomic<long long> t_tgt(0), t_src(0), t_run(0);
+    auto now = [] { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     auto align = [&](icp_ctx* c, int32_t p, bool promote) {
         const icp_pair& q = pairs[p];
         float* pose = poses_out + (size_t)p * 16;
         memcpy(pose, q.initial_pose, 64);
+        const long long a0 = times ? now() : 0;
         int rc = promote ? icp_internal_promote_source_to_target(c)
                          : icp_set_target(c, q.tgt_xyz, q.tgt_normals, q.tgt_rgba, q.n_tgt);                // buildIndex, ICPOptimizer.h:532-535
+        const long long a1 = times ? now() : 0;
         if (!rc) rc = icp_set_source(c, q.src_xyz, q.src_normals, q.src_rgba, q.n_src);
+        const long long a2 = times ? now() : 0;
         if (!rc) { int32_t n = 0; rc = icp_run(c, pose, nullptr, 0, &n); }                           // estimatePose, main.cpp:457
+        if (times) { const long long a3 = now(); t_tgt += a1 - a0; t_src += a2 - a1; t_run += a3 - a2; }
         st[(size_t)p] = rc;
         return rc;
     };
+    const long long b0 = times ? now() : 0;
     auto worker = [&](icp_ctx* c, int t) {
         if (chain) {
             const int32_t lo = (int32_t)((long long)n_pairs * t / nt), hi = (int32_t)((long long)n_pairs * (t + 1) / nt);
@@ -81,6 +92,9 @@ int icp_batch_run(icp_ctx* const* ctxs, int32_t n_ctx, const icp_pair* pairs, in
         for (int i = 0; i < nt; i++) th.emplace_back(worker, ctxs[i], i);
         for (auto& t : th) t.join();
     }
+    if (times && n_pairs > 0)
+        fprintf(stderr, "icp_batch_run: %d pairs, %d contexts, %.3f ms; per pair inside target %.3f ms, source %.3f ms, run %.3f ms (sum over threads / pairs)\n", n_pairs, nt,
+                (now() - b0) * 1e-6, t_tgt.load() * 1e-6 / n_pairs, t_src.load() * 1e-6 / n_pairs, t_run.load() * 1e-6 / n_pairs);
     int first = ICP_OK;
     for (int32_t p = 0; p < n_pairs; p++) {
         if (status_out) status_out[p] = st[(size_t)p];
