@@ -750,6 +750,9 @@ __device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, cons
 #ifndef ICP_SHARE_SPREAD
 #define ICP_SHARE_SPREAD 1       // 1: few seeded walkers in a wave -> the levels of their seeds' paths are searched side by side by the idle lanes
 #endif
+#ifndef ICP_SPREAD_TWO
+#define ICP_SPREAD_TWO 1         // 1: ... and, while the lanes suffice, the levels of the path to the last search's runner-up leaf as well
+#endif
 #define ICP_SHARE_ROWS 10        // LDS rows (of NT uint2) the shared walk needs per wave
 // The walks of one wave, shared.  A wave lasts as long as its longest walk while the lanes whose queries verified, or whose
 // walks ended early, idle.  Here an idle lane adopts a parked subtree -- the SHALLOWEST pending sibling of a lane that still walks
@@ -925,27 +928,47 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
     if (spread) {
         int* tbl = (int*)(R + 6 * NT);
         if (need_walk) tbl[__builtin_amdgcn_mbcnt_hi((unsigned int)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)wm, 0u))] = lane;
+        // Two paths per walker when the lanes suffice (ICP_SPREAD_TWO): besides the path to the seed's leaf (A) the path to the leaf the
+        // RUNNER-UP of the last search lives in (B; l2o on entry = the second leaf of the two-leaf tier, -1: none).  A query that searches
+        // although ICP has converged sits between two (or more) targets: the subtree that holds the other one survives every bound, and a
+        // helper lane would walk down to it level by level -- Lq - D dependent steps below the level D where the paths part.  Here the
+        // levels of B below D go to idle lanes as well, and B's leaf to one more: roles 0 .. Lq - 1 = the nodes of A (a node both paths
+        // pass through skips BOTH on-path children), Lq .. 2 Lq - 1 = the nodes of B (idle where B still runs with A), 2 Lq = leaf B.
+        // Every subtree that hangs off either path is tested by exactly one lane, every on-path child by the lane of the next level.
+        const bool two = ICP_SPREAD_TWO && W * (2 * Lq + 2) <= WAVE;        // (wave-uniform)
+        const int roles = two ? 2 * Lq + 1 : Lq;
         const unsigned long long im = ~wm;
         const int ri = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(im >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)im, 0u));
-        const int r = (ri * ((65536 + Lq - 1) / Lq)) >> 16, L = ri - r * Lq;           // ri / Lq, ri % Lq (exact for ri < 64)
-        const bool take = !need_walk && r < W;
+        const int r = (ri * ((65536 + roles - 1) / roles)) >> 16, role = ri - r * roles;           // ri / roles, ri % roles (exact for ri < 64, roles <= 33)
+        bool take = !need_walk && r < W;
         const int src = take ? tbl[r] : lane;
         float q[DIM];
 #pragma unroll
         for (int a = 0; a < DIM; a++) q[a] = __shfl(qp.p2[a].x, src, WAVE);
         const float sb = __shfl(wb, src, WAVE); const int si = __shfl(wi, src, WAVE), sp = __shfl(wp, src, WAVE);
+        const int sl2 = two ? __shfl(l2o, src, WAVE) : -1;
+        const int leafA = sp >> 3;
+        const bool onB = role >= Lq;                                          // a role of path B
+        const int L = role == 2 * Lq ? Lq : (onB ? role - Lq : role);
+        const int myleaf = onB ? sl2 : leafA;
+        const int nodeA = leafA >> (2 * (Lq - L)), nodeB = sl2 >> (2 * (Lq - L));      // (L == Lq: the leaves themselves)
+        if (onB && (sl2 < 0 || nodeB == nodeA)) take = false;                // B runs with A here (or there is no B): A's lane has the node
         if (take) {
 #pragma unroll
             for (int a = 0; a < DIM; a++) { qp.p2[a].x = q[a]; qp.p2[a].y = q[a]; }
             wb = sb; wi = si; wp = sp; owner = wbase + src;
             thr = fminf(wb * ICP_PRUNE_SLACK, FLT_MAX);
-            const int leaf = sp >> 3, skip = (leaf >> (2 * (Lq - L - 1))) & 3;          // the child of my node that lies on the path: the next level's lane has it
-            st.L = L; st.idx = leaf >> (2 * (Lq - L)); st.alive = true;
-            f2 l01, l23;
-            quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * L)) - 1u)) + (unsigned int)st.idx, qp, l01, l23);
-            const float inf = __uint_as_float(NONE);
-            l01.x = skip == 0 ? inf : l01.x; l01.y = skip == 1 ? inf : l01.y; l23.x = skip == 2 ? inf : l23.x; l23.y = skip == 3 ? inf : l23.y;
-            descend(l01, l23);
+            st.L = L; st.idx = myleaf >> (2 * (Lq - L)); st.alive = true;
+            if (L < Lq) {
+                const int skip = (myleaf >> (2 * (Lq - L - 1))) & 3;         // the child of my node that lies on my path: the next level's lane has it
+                const int skipB = (!onB && sl2 >= 0 && nodeB == nodeA) ? (sl2 >> (2 * (Lq - L - 1))) & 3 : skip;      // ... and B's, where B passes through this node too
+                f2 l01, l23;
+                quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * L)) - 1u)) + (unsigned int)st.idx, qp, l01, l23);
+                const float inf = __uint_as_float(NONE);
+                l01.x = (skip == 0 || skipB == 0) ? inf : l01.x; l01.y = (skip == 1 || skipB == 1) ? inf : l01.y;
+                l23.x = (skip == 2 || skipB == 2) ? inf : l23.x; l23.y = (skip == 3 || skipB == 3) ? inf : l23.y;
+                descend(l01, l23);
+            }                                                                 // (role 2 Lq: leaf B, evaluated by the loop below like any adopted leaf)
         }
         if (need_walk) { st.L = Lq; st.idx = wp >> 3; }                   // the walker itself: straight to the seed's leaf
     }

@@ -122,7 +122,7 @@ __device__ __forceinline__ void fused_search_post(const KnnParams& kp, const Bvh
     float best = FLT_MAX, lb_others = 0.f; int bi = -1, bpos = -1, q0 = in.q0;
     float4 ra = in.ra, rb = in.rb;
 #if ICP_DEBUG_TIMES
-    float dbg_lbo = 0.f, dbg_lb3 = 0.f, dbg_delta = 0.f;
+    float dbg_lbo = 0.f, dbg_lb3 = 0.f, dbg_delta = 0.f; int dbg_l2old = -1; const int dbg_q0old = in.q0;
 #endif
     bool need_walk = false, verified = false, two_leaf = false;
     float lb3 = 0.f; int l2 = -1;                         // second verification tier: bound on every target outside the neighbour's leaf and the runner-up's leaf l2
@@ -150,8 +150,14 @@ __device__ __forceinline__ void fused_search_post(const KnnParams& kp, const Bvh
                         // leaf evaluations instead of a walk.  This is what retires the queries that sit close to the bisector of two targets,
                         // which the first tier can never verify and which would otherwise walk in every iteration.
                         if (kp.qstate2) st2 = kp.qstate2[k];
+#if ICP_DEBUG_TIMES
+                        dbg_l2old = __float_as_int(st2.y);
+#endif
                         const float lb2 = (st2.x - delta) * 0.999999f;
-                        if (sbest < lb2) { two_leaf = true; lb3 = lb2; l2 = __float_as_int(st2.y); }
+                        // (a query that walks takes the runner-up's leaf along as a hint: the spread start of knn_walk_shared searches the
+                        //  path to it side by side with the path to the seed's leaf)
+                        l2 = __float_as_int(st2.y);
+                        if (sbest < lb2) { two_leaf = true; lb3 = lb2; }
                     }
                 }
             }
@@ -206,6 +212,13 @@ __device__ __forceinline__ void fused_search_post(const KnnParams& kp, const Bvh
     if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lb3, l2, bvh_lbq, tid, (ICP_DEBUG_STEPS && kp.dbg_steps) ? kp.dbg_steps + k : nullptr);
 #endif
     ICP_STAMP(2);
+#if ICP_DEBUG_TIMES
+    if (k >= 0 && need_walk && seeded) {                       // where did the seeded walk end: in the old neighbour's leaf, in the old runner-up's leaf, elsewhere?
+        GX_COUNT(8, 1);
+        if (dbg_q0old >= 0 && (bpos >> 3) == (dbg_q0old >> 3)) GX_COUNT(9, 1);
+        if (dbg_l2old >= 0 && (bpos >> 3) == dbg_l2old) GX_COUNT(10, 1);
+    }
+#endif
     asm volatile("" : "+v"(k));                           // (the addresses of this query's state and records are formed HERE, not held in registers across the walk)
     if (k >= 0) {
         // A verified query keeps its stored anchor (position of the last full search) and bound: the triangle test stays valid
