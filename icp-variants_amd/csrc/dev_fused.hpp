@@ -39,6 +39,9 @@ struct P2pGen {                                           // values 0..21 = sum 
 #ifndef ICP_WAVE_STRIDE
 #define ICP_WAVE_STRIDE ((ICP_XW && ICP_BVH_THREADS > 64) ? 128 : 0)      // 1: the waves of a block come from BVH_THREADS / 64 places of the query order (hard and easy regions meet in one block: knn_walk_shared, XW)
 #endif
+#ifndef ICP_DEBUG_WALK_ENDS
+#define ICP_DEBUG_WALK_ENDS 0
+#endif
 #ifndef ICP_DEBUG_TIMES
 #define ICP_DEBUG_TIMES 0        // (default set in dev_solve.hpp) 1 (with ICP_DEBUG_STEPS=1 for the buffer): lane 0 of every wave leaves 100 MHz timestamps of its phases in dbg_steps[8 * wave ..]
 #endif
@@ -212,7 +215,7 @@ __device__ __forceinline__ void fused_search_post(const KnnParams& kp, const Bvh
     if (need_walk) lb_others = knn_walk<DIM, BVH_THREADS>(bv, p, best, bi, bpos, lb3, l2, bvh_lbq, tid, (ICP_DEBUG_STEPS && kp.dbg_steps) ? kp.dbg_steps + k : nullptr);
 #endif
     ICP_STAMP(2);
-#if ICP_DEBUG_TIMES
+#if ICP_DEBUG_TIMES && ICP_DEBUG_WALK_ENDS                  // (one atomic per walking query on ONE word: it distorts every time stamp -- a build of its own, tools/dev_walk_ends.py)
     if (k >= 0 && need_walk && seeded) {                       // where did the seeded walk end: in the old neighbour's leaf, in the old runner-up's leaf, elsewhere?
         GX_COUNT(8, 1);
         if (dbg_q0old >= 0 && (bpos >> 3) == (dbg_q0old >> 3)) GX_COUNT(9, 1);

@@ -293,6 +293,15 @@ int ensure_match_buffers(icp_ctx* c, int n) {
 }
 
 // Morton order of the query positions [0, n) of a selection (sel == nullptr: the full source): out[t] = position.
+// rocPRIM sorts 370 k pairs with its MERGE sort (radix_sort_config's limit: 1 M items): a block sort and nine merge passes of two
+// launches each -- 19 launches of ~8 us per sort, four sorts per scan (three axis orders for the index, the Morton order of the queries).
+// ICP_SORT_MERGE_LIMIT=0 sends them to the Onesweep radix sort instead (a histogram launch and one pass per 8 key bits).  Measured
+// (round 3, same results -- both are stable): icp_set_target 1.34-1.39 ms against 1.31-1.35, the first icp_run (Morton sort of 64-bit
+// keys) 1.88 against 1.76-1.79 ms, a batch of 16 pairs 480-523 against 523-541 pairs/s: fewer launches, more time.  Merge sort stays.
+#ifndef ICP_SORT_MERGE_LIMIT
+#define ICP_SORT_MERGE_LIMIT (1024 * 1024)
+#endif
+using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, ICP_SORT_MERGE_LIMIT>;
 int build_query_order(icp_ctx* c, const int* d_sel, int n, DevBuf& out) {
     int rc;
     if ((rc = ensure(c, c->okeys, (size_t)n * 8))) return rc;
@@ -302,9 +311,9 @@ int build_query_order(icp_ctx* c, const int* d_sel, int n, DevBuf& out) {
     hipLaunchKernelGGL(k_query_keys, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->src.x.as<float>(), c->src.y.as<float>(), c->src.z.as<float>(), d_sel, n,
                        c->src_box.as<unsigned int>(), c->okeys.as<unsigned long long>(), c->ovals.as<int>());
     size_t temp_bytes = 0;
-    HIPCK(c, rocprim::radix_sort_pairs(nullptr, temp_bytes, c->okeys.as<unsigned long long>(), c->okeys2.as<unsigned long long>(), c->ovals.as<int>(), out.as<int>(), (size_t)n, 0, 64, c->stream));
+    HIPCK(c, rocprim::radix_sort_pairs<SortCfg>(nullptr, temp_bytes, c->okeys.as<unsigned long long>(), c->okeys2.as<unsigned long long>(), c->ovals.as<int>(), out.as<int>(), (size_t)n, 0, 64, c->stream));
     if ((rc = ensure(c, c->otemp, temp_bytes))) return rc;
-    HIPCK(c, rocprim::radix_sort_pairs(c->otemp.p, temp_bytes, c->okeys.as<unsigned long long>(), c->okeys2.as<unsigned long long>(), c->ovals.as<int>(), out.as<int>(), (size_t)n, 0, 64, c->stream));
+    HIPCK(c, rocprim::radix_sort_pairs<SortCfg>(c->otemp.p, temp_bytes, c->okeys.as<unsigned long long>(), c->okeys2.as<unsigned long long>(), c->ovals.as<int>(), out.as<int>(), (size_t)n, 0, 64, c->stream));
     HIPCK(c, hipGetLastError());
     return ICP_OK;
 }
@@ -339,7 +348,7 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
         // finite targets in index order (device list from icp_set_target)
         HIPCK(c, hipMemcpyAsync(perm, b.d_finite, (size_t)nv * 4, hipMemcpyDeviceToDevice, c->stream));
         size_t temp_bytes = 0;
-        HIPCK(c, rocprim::radix_sort_pairs(nullptr, temp_bytes, b.keys.as<unsigned long long>(), b.keys2.as<unsigned long long>(), perm, perm2, (size_t)nv, 0, 64, c->stream));
+        HIPCK(c, rocprim::radix_sort_pairs<SortCfg>(nullptr, temp_bytes, b.keys.as<unsigned long long>(), b.keys2.as<unsigned long long>(), perm, perm2, (size_t)nv, 0, 64, c->stream));
         if ((rc = ensure(c, b.temp, temp_bytes))) return rc;
         const int gb = (nv + 255) / 256;
         int d_first = 0;
@@ -353,7 +362,7 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
                 if ((rc = ensure(c, b.axis_of_node, (size_t)1 << n_upper))) return rc;
                 unsigned int* k32 = b.keys.as<unsigned int>(); unsigned int* k32b = b.keys2.as<unsigned int>();
                 size_t tb = 0;
-                HIPCK(c, rocprim::radix_sort_pairs(nullptr, tb, k32, k32b, perm, perm2, (size_t)nv, 0, 32, c->stream));
+                HIPCK(c, rocprim::radix_sort_pairs<SortCfg>(nullptr, tb, k32, k32b, perm, perm2, (size_t)nv, 0, 32, c->stream));
                 if ((rc = ensure(c, b.temp, tb > temp_bytes ? tb : temp_bytes))) return rc;
                 const int nblk = (nv + PRS_THREADS - 1) / PRS_THREADS;
                 if ((rc = ensure(c, b.scanr, (size_t)2 * DIM * nblk * 4))) return rc;
@@ -362,7 +371,7 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
                 for (int k = 0; k < DIM; k++) {           // one stable sort per axis (ids arrive in increasing order: ties keep index order)
                     cur[k] = b.axl[k].as<int>(); alt[k] = b.axl[DIM + k].as<int>();
                     hipLaunchKernelGGL(k_axis_keys, dim3(gb), dim3(256), 0, c->stream, cp.c[k], b.d_finite, nv, k32);
-                    HIPCK(c, rocprim::radix_sort_pairs(b.temp.p, tb, k32, k32b, b.d_finite, cur[k], (size_t)nv, 0, 32, c->stream));
+                    HIPCK(c, rocprim::radix_sort_pairs<SortCfg>(b.temp.p, tb, k32, k32b, b.d_finite, cur[k], (size_t)nv, 0, 32, c->stream));
                 }
                 for (int d = 0; d < n_upper; d++) {
                     int sh = 0; { long long seg = (long long)BVH_LEAF * b.Lp >> d; while ((1LL << sh) < seg) sh++; }
@@ -398,7 +407,7 @@ int build_bvh(icp_ctx* c, Bvh& b, const CoordPtrs<DIM>& cp) {
                 hipLaunchKernelGGL(k_bvh_wave_boxes<DIM>, dim3(gb), dim3(256), 0, c->stream, cp, perm, nv, seg_shift, b.lvl.as<unsigned int>());
             }
             hipLaunchKernelGGL(k_bvh_level_keys<DIM>, dim3(gb), dim3(256), 0, c->stream, cp, perm, nv, seg_shift, b.lvl.as<unsigned int>(), b.keys.as<unsigned long long>());
-            HIPCK(c, rocprim::radix_sort_pairs(b.temp.p, temp_bytes, b.keys.as<unsigned long long>(), b.keys2.as<unsigned long long>(), perm, perm2, (size_t)nv, 0, 32 + d, c->stream));
+            HIPCK(c, rocprim::radix_sort_pairs<SortCfg>(b.temp.p, temp_bytes, b.keys.as<unsigned long long>(), b.keys2.as<unsigned long long>(), perm, perm2, (size_t)nv, 0, 32 + d, c->stream));
             int* t = perm; perm = perm2; perm2 = t;
         }
     }

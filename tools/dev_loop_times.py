@@ -19,7 +19,7 @@ a, _, _ = c.iteration_times()
 print("iteration times (us):", np.round(a * 1000, 1).tolist())
 buf = np.zeros(n, np.int32)
 assert c.lib.icp_debug_steps(c.h, buf.ctypes.data_as(C.c_void_p), C.c_int32(n)) == 0
-nb = (n + 127) // 128; nw = nb * 2; nred = 68
+BT = int(os.environ.get("ICP_DEV_BVH_THREADS", "256")); nb = (n + BT - 1) // BT; nw = nb * (BT // 64); nred = 68      # as the library under test was built
 wraw = buf[: nw * 8].reshape(nw, 8)
 w = wraw[:, :5].astype(np.uint32).astype(np.int64)
 r = buf[nw * 8: (nw + 2 * nred) * 8].reshape(2 * nred, 8)[:, :5].astype(np.uint32).astype(np.int64)

@@ -1,4 +1,4 @@
-"""Dev tool (times build): where do the seeded walks of the last launch of a run end -- in the old neighbour's leaf, in the old runner-up's leaf
+"""Dev tool (a build with ICP_DEBUG_STEPS=1 ICP_DEBUG_TIMES=1 ICP_DEBUG_WALK_ENDS=1): where do the seeded walks of the last launch of a run end -- in the old neighbour's leaf, in the old runner-up's leaf
 (the second leaf of the two-leaf tier), or elsewhere?  usage: ICP_HIP_LIB=.../libicp_hip_times.so python tools/dev_walk_ends.py [iterations ...]"""
 import sys, os, ctypes as C
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))

@@ -15,6 +15,8 @@ run bench_lbvh_alltimed python bench.py --stage-timing 1 --no-cpu-baseline
 run bench_lbvh_nostageevents python bench.py --stage-timing 0 --no-cpu-baseline
 run bench_brute python bench.py --knn brute --steps 2 --no-cpu-baseline
 run bench_batch16 python bench.py --pairs 16 --steps 3 --warmup 1
+run bench_batch16_shared python bench.py --pairs 16 --steps 3 --warmup 1 --shared-scans
+run bench_batch44_shared python bench.py --pairs 44 --steps 2 --warmup 1 --shared-scans
 run bench_lbvh_2pairs python bench.py --resident-pairs 2 --no-cpu-baseline
 echo "== kernel trace"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $OUT/kt.log 2>&1 || exit 1
@@ -39,6 +41,7 @@ PY
 if [ -f icp-variants_amd/lib/libicp_hip_times.so ]; then      # development build with per-wave phase stamps (ICP_DEBUG_STEPS=1 ICP_DEBUG_TIMES=1), built before the call
   echo "== wave phase times"
   ICP_HIP_MERGE=0 ICP_HIP_LIB=icp-variants_amd/lib/libicp_hip_times.so timeout -k 10 300 python tools/dev_wave_times.py 1 3 6 12 20 45 > $OUT/wave_phase_times.txt 2> $OUT/wave_phase_times.err
+  ICP_HIP_LIB=icp-variants_amd/lib/libicp_hip_times.so timeout -k 10 300 python tools/dev_ring_times.py 3 12 30 40 > $OUT/ring_phase_times.txt 2> $OUT/ring_phase_times.err
   for it in 2 12 30 40; do ICP_HIP_PERSIST=1 ICP_HIP_LOOP_WAVESLEEP=6 ICP_HIP_DBG_ITER=$it ICP_HIP_LIB=icp-variants_amd/lib/libicp_hip_times.so timeout -k 10 300 python tools/dev_loop_times.py; done > $OUT/loop_phase_times.txt 2> $OUT/loop_phase_times.err
 fi
 rm -rf $OUT/kt $OUT/ktb $OUT/pmc/p*/
