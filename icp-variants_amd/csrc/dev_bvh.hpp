@@ -829,6 +829,10 @@ constexpr unsigned long long GX_EMPTY = ~0ull;
 #if defined(ICP_DEBUG_TIMES) && ICP_DEBUG_TIMES
 __device__ unsigned int g_gx_dbg[16];    // development builds: 0 posted, 1 claimed by helpers, 2 taken back, 3 results folded, 4 helper waves, 5 helper rounds, 6 helper rounds with a claim
 #define GX_COUNT(i, n) atomicAdd(&g_gx_dbg[i], (unsigned int)(n))
+#ifndef ICP_DEBUG_WALK_TRACE
+#define ICP_DEBUG_WALK_TRACE 0
+#endif
+__device__ unsigned int g_walk_trace[64];   // ICP_DEBUG_WALK_TRACE: the last sparse walk (<= 3 walkers in the wave: spread start) of the launch: 0 walkers, 1 paths per walker, 2 clock at entry, 3 after the spread, 4 passes, 5 polls, 6 clock at exit, 8.. clock at the top of every pass (tools/dev_walk_trace.py)
 #else
 #define GX_COUNT(i, n)
 #endif
@@ -903,6 +907,10 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
     // seed's bound -- handed on below like any other parked subtree.
     const unsigned long long wm = __ballot(need_walk);
     const int W = __popcll(wm);
+#if ICP_DEBUG_TIMES && ICP_DEBUG_WALK_TRACE
+    const bool tracer = !HELP && !PROXY && W > 0 && W <= 3 && lane == (int)__ffsll((long long)wm) - 1;
+    if (tracer) { g_walk_trace[0] = (unsigned int)W; g_walk_trace[2] = (unsigned int)wall_clock64(); }
+#endif
     if (MODE == 1 && lane == 0) __hip_atomic_fetch_add(xc + 0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // nreg: this wave has queries that search
     const bool spread = !HELP && !PROXY && ICP_SHARE_SPREAD && Lq > 0 && W > 0 && W * (Lq + 1) <= WAVE && wm == __ballot(need_walk && wp >= 0);
     if (ICP_PREFETCH_PATH && !spread && need_walk && wp >= 0) touched = quad_prefetch_path<DIM>(bv, wp >> 3);
@@ -937,6 +945,9 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
         // Every subtree that hangs off either path is tested by exactly one lane, every on-path child by the lane of the next level.
         const bool two = ICP_SPREAD_TWO && W * (2 * Lq + 2) <= WAVE;        // (wave-uniform)
         const int roles = two ? 2 * Lq + 1 : Lq;
+#if ICP_DEBUG_TIMES && ICP_DEBUG_WALK_TRACE
+        if (tracer) g_walk_trace[1] = two ? 2u : 1u;
+#endif
         const unsigned long long im = ~wm;
         const int ri = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(im >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)im, 0u));
         const int r = (ri * ((65536 + roles - 1) / roles)) >> 16, role = ri - r * roles;           // ri / roles, ri % roles (exact for ri < 64, roles <= 33)
@@ -972,10 +983,16 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
         }
         if (need_walk) { st.L = Lq; st.idx = wp >> 3; }                   // the walker itself: straight to the seed's leaf
     }
+#if ICP_DEBUG_TIMES && ICP_DEBUG_WALK_TRACE
+    if (tracer) g_walk_trace[3] = (unsigned int)wall_clock64();
+#endif
     bool polling = false;                                                 // XW, wave-uniform: this wave is counted in idlew
     int polls = 0, trips = 0;
     for (;;) {
         trips++;
+#if ICP_DEBUG_TIMES && ICP_DEBUG_WALK_TRACE
+        if (tracer && trips < 56) g_walk_trace[7 + trips] = (unsigned int)wall_clock64();
+#endif
         if (!st.alive && owner >= 0) {
             // this lane's (part of the) search is over: fold it into the owner's record.  Winner: 64-bit minimum of (distance, index).
             // Runner-up entry (distance, leaf): 64-bit minimum as well; whatever loses there -- and is not in the same leaf as what beat
@@ -1204,6 +1221,9 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
         }
     }
     if (XW && polling && lane == 0) __hip_atomic_fetch_sub(xc + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#if ICP_DEBUG_TIMES && ICP_DEBUG_WALK_TRACE
+    if (tracer) { g_walk_trace[4] = (unsigned int)trips; g_walk_trace[5] = (unsigned int)polls; g_walk_trace[6] = (unsigned int)wall_clock64(); }
+#endif
     asm volatile("" ::"v"(touched));
     if (HELP) return;
     if (PROXY) {                                                          // raw: what the owner folds like the result of one of its own lanes

@@ -1603,6 +1603,7 @@ int icp_debug_gx_counters(icp_ctx* c, uint32_t* out16, int32_t reset) {     // d
     if ((rc = set_device(c))) return rc;
     HIPCK(c, hipStreamSynchronize(c->stream));
     HIPCK(c, hipMemcpyFromSymbol(out16, HIP_SYMBOL(icpdev::g_gx_dbg), 64));
+    if (reset == 2) HIPCK(c, hipMemcpyFromSymbol(out16, HIP_SYMBOL(icpdev::g_walk_trace), 256));      // (reset == 2: the caller's buffer has 64 words and wants the trace of the last sparse walk instead, tools/dev_walk_trace.py)
     if (reset) { uint32_t z[16] = {0}; HIPCK(c, hipMemcpyToSymbol(HIP_SYMBOL(icpdev::g_gx_dbg), z, 64)); }
     return ICP_OK;
 #else
