@@ -23,6 +23,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k
 find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/lbvh_kernel_stats.csv \;
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktb -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --knn brute > $OUT/ktb.log 2>&1 || exit 1
 find $OUT/ktb -name "*kernel_stats.csv" -exec cp {} $OUT/brute_kernel_stats.csv \;
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ktp -- python bench.py --pairs 16 --steps 2 --warmup 1 --shared-scans > $OUT/ktp.log 2>&1 || exit 1
+find $OUT/ktp -name "*kernel_stats.csv" -exec cp {} $OUT/batch16_kernel_stats.csv \;
 echo "== pmc passes"
 timeout -k 10 900 bash tools/pmc_passes.sh $OUT/pmc lbvh 50 > $OUT/pmc.log 2>&1 || exit 1
 cp $OUT/pmc/summary.csv $OUT/lbvh_pmc_summary.csv
@@ -44,5 +46,5 @@ if [ -f icp-variants_amd/lib/libicp_hip_times.so ]; then      # development buil
   ICP_HIP_LIB=icp-variants_amd/lib/libicp_hip_times.so timeout -k 10 300 python tools/dev_ring_times.py 3 12 30 40 > $OUT/ring_phase_times.txt 2> $OUT/ring_phase_times.err
   for it in 2 12 30 40; do ICP_HIP_PERSIST=1 ICP_HIP_LOOP_WAVESLEEP=6 ICP_HIP_DBG_ITER=$it ICP_HIP_LIB=icp-variants_amd/lib/libicp_hip_times.so timeout -k 10 300 python tools/dev_loop_times.py; done > $OUT/loop_phase_times.txt 2> $OUT/loop_phase_times.err
 fi
-rm -rf $OUT/kt $OUT/ktb $OUT/pmc/p*/
+rm -rf $OUT/kt $OUT/ktb $OUT/ktp $OUT/pmc/p*/
 echo done
