@@ -750,6 +750,9 @@ __device__ __forceinline__ void knn_store_state(const KnnParams& kp, int k, cons
 #ifndef ICP_SHARE_SPREAD
 #define ICP_SHARE_SPREAD 1       // 1: few seeded walkers in a wave -> the levels of their seeds' paths are searched side by side by the idle lanes
 #endif
+#ifndef ICP_LONE_WALK
+#define ICP_LONE_WALK 1          // 1: a wave with ONE (seeded) walker searches level-synchronously, two levels per dependent load (knn_walk_shared)
+#endif
 #ifndef ICP_SPREAD_TWO
 #define ICP_SPREAD_TWO 1         // 1: ... and, while the lanes suffice, the levels of the path to the last search's runner-up leaf as well
 #endif
@@ -883,11 +886,108 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
         R[2 * NT + lane] = make_uint2(FMAXB, 0xFFFFFFFFu);                 // row 2: (bound on the rest, position of the winner)
         ((unsigned int*)(R + 6 * NT))[WAVE + lane] = FMAXB;                // row 6, second half: smallest skipped box bound
     }
+    // (the fold of one lane's part of a search into the owner's record: see the comment where the loop below calls it)
+    auto fold_part = [&](int owner, float wb, int wi, int wp, float b2, int l2, float b3, unsigned int mlb) {
+        const unsigned long long mykey = ((unsigned long long)__float_as_uint(wb) << 32) | (unsigned int)wi;
+        const unsigned long long old = __hip_atomic_fetch_min(keys + owner, mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        unsigned int* bp = (unsigned int*)(lbq + 2 * NT + owner);     // {rest, position}
+        unsigned int rest = __float_as_uint(b3);
+        unsigned long long e = ((unsigned long long)__float_as_uint(b2) << 32) | (unsigned int)l2;
+        if (old < mykey) {
+            const unsigned long long w = ((unsigned long long)__float_as_uint(wb) << 32) | (unsigned int)(wp >> 3);
+            const unsigned long long lo = w < e ? w : e, hi = w < e ? e : w;
+            if ((unsigned int)lo != (unsigned int)hi) rest = min(rest, (unsigned int)(hi >> 32));
+            e = lo;
+        } else if (old > mykey && old != ~0ull) rest = min(rest, (unsigned int)(old >> 32));
+        {
+            const unsigned long long o2 = __hip_atomic_fetch_min(keys + NT + owner, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned long long lo = o2 < e ? o2 : e, hi = o2 < e ? e : o2;
+            if (hi != ~0ull && (unsigned int)lo != (unsigned int)hi) rest = min(rest, (unsigned int)(hi >> 32));
+        }
+        __hip_atomic_fetch_min(bp, rest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_min((unsigned int*)(lbq + 6 * NT + (owner & ~63)) + WAVE + (owner & 63), mlb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (__hip_atomic_load(keys + owner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == mykey) bp[1] = (unsigned int)wp;      // (XW: see the check at the end)
+    };
+    // ---- ONE walker in the wave (every converged launch that has a walking query at all, most waves of the late iterations): no hand-over,
+    // no seed path -- the wave searches the tree for that one query level-synchronously from the root, TWO levels per dependent load.  An
+    // item is (node n of level L, child j): its lane loads n and n's child j in the same trip, tests box j of n and, if that survives, the
+    // four boxes in the child; the surviving grandchildren are the nodes of the next step (four items each).  A walk of Lq = 8 levels is
+    // four trips and one for the leaves, against a dozen dependent loads of the general path (tools/dev_walk_trace.py: 7.3-7.9 us for the
+    // one query that makes a converged launch last 19.7 instead of 14.2 us).  The frontier lives in the wave's 64-entry table: more than
+    // 16 nodes on a level (64 leaves at the end) and the wave takes the general path instead -- nothing has been folded by then.  Every
+    // box is tested against the seed's radius (a seeded walk is a range query: the radius is all but final), every evaluated leaf is
+    // folded into the walker's record like a helper lane's, every pruned box goes to the skipped-bound minimum: the same record, the same
+    // exact neighbour, bounds that are valid in the same way.
+    bool lone_done = false;
+    const unsigned long long wm0 = __ballot(need_walk);
+    if (ICP_LONE_WALK && MODE == 1 && DIM == 3 && sizeof(MaskT) == 4 && ICP_SHARE_SPREAD && Lq > 0 && __popcll(wm0) == 1 && wm0 == __ballot(need_walk && bpos >= 0)) {
+        int* tbl = (int*)(R + 6 * NT);
+        const int wl = (int)__ffsll((long long)wm0) - 1;
+        QueryPt<DIM> lq;
+#pragma unroll
+        for (int a = 0; a < DIM; a++) { const float v = __shfl(p[a], wl, WAVE); lq.p2[a].x = v; lq.p2[a].y = v; }
+        const float sb = __shfl(best, wl, WAVE); const int si = __shfl(bi, wl, WAVE), sp = __shfl(bpos, wl, WAVE);
+        const float thr_u = fminf(sb * ICP_PRUNE_SLACK, FLT_MAX);
+        unsigned int lmlb = FMAXB;
+        int nf = 1, L = 0; bool ok = true;
+        if (lane == 0) tbl[0] = 0;
+        while (L < Lq && ok) {
+            const int items = nf * 4;
+            const bool act = lane < items;
+            const int n = act ? tbl[lane >> 2] : 0, j = lane & 3;
+            f2 a01, a23;
+            quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * L)) - 1u)) + (unsigned int)n, lq, a01, a23);
+            const float lbj = j == 0 ? a01.x : j == 1 ? a01.y : j == 2 ? a23.x : a23.y;
+            const bool alive = act && !(lbj > thr_u);
+            if (act && !alive) lmlb = min(lmlb, __float_as_uint(lbj));
+            const int c = 4 * n + j;
+            if (L + 2 <= Lq) {                                            // (wave-uniform) the children are nodes: their boxes in the same trip
+                f2 g01, g23;
+                quad_lb_at<DIM>(bv, (0x55555555u & ((1u << (2 * (L + 1))) - 1u)) + (unsigned int)(act ? c : 0), lq, g01, g23);
+                const bool s0 = alive && !(g01.x > thr_u), s1 = alive && !(g01.y > thr_u), s2 = alive && !(g23.x > thr_u), s3 = alive && !(g23.y > thr_u);
+                if (alive) lmlb = min(min(lmlb, min(s0 ? NONE : __float_as_uint(g01.x), s1 ? NONE : __float_as_uint(g01.y))), min(s2 ? NONE : __float_as_uint(g23.x), s3 ? NONE : __float_as_uint(g23.y)));
+                const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1), m2 = __ballot(s2), m3 = __ballot(s3);
+                const int c0 = __popcll(m0), c1 = __popcll(m1), c2 = __popcll(m2), nn = c0 + c1 + c2 + __popcll(m3);
+                ok = nn <= (L + 2 < Lq ? 16 : WAVE);                       // (uniform)
+                if (ok) {
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    if (s0) tbl[__popcll(m0 & below)] = 4 * c;
+                    if (s1) tbl[c0 + __popcll(m1 & below)] = 4 * c + 1;
+                    if (s2) tbl[c0 + c1 + __popcll(m2 & below)] = 4 * c + 2;
+                    if (s3) tbl[c0 + c1 + c2 + __popcll(m3 & below)] = 4 * c + 3;
+                }
+                nf = nn; L += 2;
+            } else {                                                       // the children are the leaves
+                const unsigned long long m = __ballot(alive);
+                if (alive) tbl[__popcll(m & ((1ull << lane) - 1ull))] = c;
+                nf = __popcll(m); L += 1;
+            }
+        }
+        if (ok) {
+            if (lane < nf) {
+                const int leaf = tbl[lane];
+                float xb = sb, x2 = FLT_MAX, x3 = FLT_MAX; int xi = si, xp = sp, xl = -1;
+                leaf_eval<DIM>(bv.leaves + leaf, leaf, lq.p2, xb, xi, xp, x2, xl, x3);
+                fold_part(wbase + wl, xb, xi, xp, x2, xl, x3, lmlb);
+            } else __hip_atomic_fetch_min((unsigned int*)(lbq + 6 * NT + wbase) + WAVE + wl, lmlb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // (XW: the wave has not registered as searching -- it neither offers nor needs help)
+            lone_done = true;
+        }
+    }
     QueryPt<DIM> qp;
-    make_query<DIM>(bv, p, qp);
-    float wb = best; int wi = bi, wp = bpos;
+    float wb; int wi, wp;
+    if constexpr (DIM == 3 && MODE == 1 && sizeof(MaskT) == 4 && ICP_LONE_WALK) {
+        // (read back from the rows written above rather than kept in registers across the lone walker's search: six registers of the budget)
+        const uint2 ra_ = R[3 * NT + lane], rb_ = R[4 * NT + lane], rc_ = R[5 * NT + lane], rd_ = R[7 * NT + lane];
+        float pq[3] = {__uint_as_float(rc_.y), __uint_as_float(rd_.x), __uint_as_float(rd_.y)};
+        make_query<DIM>(bv, pq, qp);
+        wb = __uint_as_float(ra_.x); wi = (int)ra_.y; wp = (int)rb_.x;
+    } else {
+        make_query<DIM>(bv, p, qp);
+        wb = best; wi = bi; wp = bpos;
+    }
     unsigned int touched = 0u;
-    if (!HELP && need_walk) {
+    if (!HELP && need_walk && !lone_done) {
         if (ICP_SEED_DESCENT && wp < 0) {                                 // first iteration: a greedy descent yields a real candidate (see knn_walk)
             int idx = 0;
             for (int L = 0; L < Lq; L++) {
@@ -911,7 +1011,7 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
     const bool tracer = !HELP && !PROXY && W > 0 && W <= 3 && lane == (int)__ffsll((long long)wm) - 1;
     if (tracer) { g_walk_trace[0] = (unsigned int)W; g_walk_trace[2] = (unsigned int)wall_clock64(); }
 #endif
-    if (MODE == 1 && lane == 0) __hip_atomic_fetch_add(xc + 0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // nreg: this wave has queries that search
+    if (MODE == 1 && lane == 0 && !lone_done) __hip_atomic_fetch_add(xc + 0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // nreg: this wave has queries that search
     const bool spread = !HELP && !PROXY && ICP_SHARE_SPREAD && Lq > 0 && W > 0 && W * (Lq + 1) <= WAVE && wm == __ballot(need_walk && wp >= 0);
     if (ICP_PREFETCH_PATH && !spread && need_walk && wp >= 0) touched = quad_prefetch_path<DIM>(bv, wp >> 3);
     float b2 = FLT_MAX, b3 = FLT_MAX; int l2 = -1;
@@ -933,7 +1033,7 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
         } else st.alive = false;
         quad_pop_bits(st);
     };
-    if (spread) {
+    if (spread && !lone_done) {
         int* tbl = (int*)(R + 6 * NT);
         if (need_walk) tbl[__builtin_amdgcn_mbcnt_hi((unsigned int)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)wm, 0u))] = lane;
         // Two paths per walker when the lanes suffice (ICP_SPREAD_TWO): besides the path to the seed's leaf (A) the path to the leaf the
@@ -988,7 +1088,7 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
 #endif
     bool polling = false;                                                 // XW, wave-uniform: this wave is counted in idlew
     int polls = 0, trips = 0;
-    for (;;) {
+    for (; !lone_done;) {                                                 // (a lone walker's search is over already)
         trips++;
 #if ICP_DEBUG_TIMES && ICP_DEBUG_WALK_TRACE
         if (tracer && trips < 56) g_walk_trace[7 + trips] = (unsigned int)wall_clock64();
@@ -999,25 +1099,7 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
             // it: such a point is bounded by that entry for as long as it stands, and by its distance in the rest once it falls -- goes to
             // the bound on the rest.  A winner of mine that loses is an entry of its own leaf; a winner I dethrone has no leaf on record:
             // straight to the rest (smaller bound than needed, for this one iteration).
-            const unsigned long long mykey = ((unsigned long long)__float_as_uint(wb) << 32) | (unsigned int)wi;
-            const unsigned long long old = __hip_atomic_fetch_min(keys + owner, mykey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            unsigned int* bp = (unsigned int*)(lbq + 2 * NT + owner);     // {rest, position}
-            unsigned int rest = __float_as_uint(b3);
-            unsigned long long e = ((unsigned long long)__float_as_uint(b2) << 32) | (unsigned int)l2;
-            if (old < mykey) {
-                const unsigned long long w = ((unsigned long long)__float_as_uint(wb) << 32) | (unsigned int)(wp >> 3);
-                const unsigned long long lo = w < e ? w : e, hi = w < e ? e : w;
-                if ((unsigned int)lo != (unsigned int)hi) rest = min(rest, (unsigned int)(hi >> 32));
-                e = lo;
-            } else if (old > mykey && old != ~0ull) rest = min(rest, (unsigned int)(old >> 32));
-            {
-                const unsigned long long o2 = __hip_atomic_fetch_min(keys + NT + owner, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const unsigned long long lo = o2 < e ? o2 : e, hi = o2 < e ? e : o2;
-                if (hi != ~0ull && (unsigned int)lo != (unsigned int)hi) rest = min(rest, (unsigned int)(hi >> 32));
-            }
-            __hip_atomic_fetch_min(bp, rest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_min((unsigned int*)(lbq + 6 * NT + (owner & ~63)) + WAVE + (owner & 63), mlb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (__hip_atomic_load(keys + owner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == mykey) bp[1] = (unsigned int)wp;      // (XW: see the check at the end)
+            fold_part(owner, wb, wi, wp, b2, l2, b3, mlb);
             if (XW && (owner >> 6) != myw) __hip_atomic_fetch_sub(xc + 4 + (owner >> 6), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             owner = -1;
         }
