@@ -973,6 +973,9 @@ __device__ __forceinline__ void knn_walk_shared(const BvhViewT<DIM>& bv, float* 
             // (XW: the wave has not registered as searching -- it neither offers nor needs help)
             lone_done = true;
         }
+#if ICP_DEBUG_TIMES
+        if (lane == 0) GX_COUNT(ok ? 11 : 12, 1);                         // development builds: lone searches completed / started over on the general path
+#endif
     }
     QueryPt<DIM> qp;
     float wb; int wi, wp;

@@ -150,6 +150,44 @@ def test_seeded_search_on_tie_clouds_vs_brute_force_oracle(gpu_ctx_factory, orc,
     c.close()
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_seeded_search_lone_walkers_small_and_huge_radius(gpu_ctx_factory, orc, seed):
+    """Waves with exactly ONE walker take the level-synchronous search (knn_walk_shared, ICP_LONE_WALK): most queries sit on the target
+    surface and verify from the second launch on; a sprinkling of queries on the bisector of two targets keeps walking with a small
+    radius (the frontier stays small: the lone search completes), a few far outliers keep walking with a larger one, and one query sits at the centre
+    of a spherical shell of 4 000 targets (every box of the shell survives: the frontier overflows and the wave must start over on the general
+    path -- tools/dev_lone_counts.py counts both outcomes on this very cloud).  The motion shrinks but never stops, so both kinds walk
+    in every launch.  idx / d2 of several launches of the chain against the oracle's brute-force scan."""
+    rng = np.random.default_rng(9100 + seed)
+    nt = 30000 + 5000 * seed
+    tgt = np.c_[rng.uniform(-2, 2, (nt, 2)), rng.normal(0, 2e-3, nt)].astype(f32)
+    v = rng.normal(size=(4000, 3)); shell = np.array([10.0, 10.0, 10.0]) + v / np.linalg.norm(v, axis=1, keepdims=True) * (1.0 + rng.normal(0, 1e-4, (4000, 1)))
+    n_close, n_bis, n_far = 6000, 60, 12
+    close = tgt[rng.integers(0, nt, n_close)] + rng.normal(0, 1e-4, (n_close, 3))
+    a = tgt[rng.integers(0, nt, n_bis)]
+    d = np.linalg.norm(tgt[None, :, :2] - a[:, None, :2], axis=2); d[d == 0] = np.inf
+    b = tgt[np.argmin(d, axis=1)]                           # a near neighbour on the surface: the query between them has two candidates
+    bis = 0.5 * (a.astype(np.float64) + b.astype(np.float64))
+    far = np.c_[rng.uniform(-2, 2, (n_far, 2)), rng.uniform(1.5, 3.0, n_far)]
+    tgt = np.r_[tgt, shell.astype(f32)]; nt = len(tgt)       # ... and ONE query at the centre of a shell of 4 000 targets: every box of the shell survives its radius
+    src = np.r_[close, bis, far, np.array([[10.0, 10.0, 10.0]])]
+    src = src[rng.permutation(len(src))].astype(f32)
+    v = rng.normal(size=(nt, 3)); tn = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(f32)
+    v = rng.normal(size=(len(src), 3)); sn = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(f32)
+    c = gpu_ctx_factory()
+    c.params.max_distance = 100.0; c.params.metric = 1; c.params.rejection = 0; c.params.knn_backend = LBVH; c.push_params()
+    c.set_target(tgt, tn); c.set_source(src, sn)
+    poses = [np.eye(4, dtype=f32)]
+    for j in range(7):
+        poses.append((small_motion(rng, max(0.01 * 0.3 ** j, 2e-5)) @ poses[-1].astype(np.float64)).astype(f32))
+    for upto in (2, 4, 5, 7):
+        m, d2 = c.match_seeded(poses[: upto + 1])
+        mo, do = orc.knn3(orc.transform_points(src, poses[upto]), tgt, 100.0)
+        assert np.array_equal(m["idx"], mo["idx"]), (upto, int((m["idx"] != mo["idx"]).sum()))
+        assert np.array_equal(d2.view(np.uint32), do.view(np.uint32)), upto
+    c.close()
+
+
 def test_seeded_search_colour_6d_vs_oracle(gpu_ctx_factory, orc):
     """The 6-D instantiation of the same fused matcher (colour ICP), seeded: bit-exact against the oracle's 6-D scan."""
     from icp_amd import synth
